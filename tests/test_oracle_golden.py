@@ -1,0 +1,107 @@
+"""Pin the CPU oracle against the golden vectors produced by the real reference
+(tests/golden/make_golden.py).  Forward tolerance 1e-5 abs; the
+fp32-vs-fp64 noise floor of the reference itself is ~4e-6."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import nerfw_oracle as orc
+
+TOL = 1e-5
+
+
+def test_g1_posenc():
+    cfg, a = gu.load("g1_posenc")
+    for n in cfg["n_freqs"]:
+        got = orc.posenc(a["x"], n)
+        assert got.shape == a[f"out_{n}"].shape
+        assert torch.equal(got, a[f"out_{n}"])
+
+
+@pytest.mark.parametrize("name", gu.golden_names("g2_field_"))
+def test_g2_field(name):
+    cfg, a = gu.load(name)
+    spec = orc.FieldSpec(**cfg["spec"])
+    P = orc.make_field_params(spec, cfg["seed"], cfg["regime"])
+    got = orc.field_forward_packed(spec, P, a["x"], sigma_only=cfg["sigma_only"],
+                                   output_transient=cfg["output_transient"])
+    assert got.shape == a["y"].shape
+    assert (got - a["y"]).abs().max().item() <= TOL
+
+
+def test_g3_sample_pdf():
+    cfg, a = gu.load("g3_sample_pdf")
+    I = cfg["n_importance"]
+    R = a["bins"].shape[0]
+    det = orc.sample_pdf(a["bins"], a["weights"], torch.linspace(0, 1, I).expand(R, I))
+    assert torch.equal(det, a["det"])
+    rnd = orc.sample_pdf(a["bins"], a["weights"], a["u"])
+    assert torch.equal(rnd, a["rnd"])
+
+
+RENDER = [n for n in gu.golden_names("g") if n[:2] in ("g4", "g5", "g6", "g7", "g8", "g9")
+          or n.startswith(("g10", "g12", "g13"))]
+
+
+@pytest.mark.parametrize("name", RENDER)
+def test_render_forward(name):
+    cfg, a = gu.load(name)
+    (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
+    with torch.no_grad():
+        res = orc.render_rays(spec_c, P_c, spec_f, P_f, a["rays"], **kw)
+    assert list(res.keys()) == cfg["keys"], "dict key order must match the reference"
+    for k in cfg["keys"]:
+        exp = a["out." + k]
+        assert res[k].shape == exp.shape, k
+        err = (res[k] - exp).abs().max().item()
+        assert err <= TOL, f"{name}:{k} max abs err {err:.3e}"
+
+
+GRAD = gu.golden_names("g11_") + ["g12_stoch_grad"]
+
+
+@pytest.mark.parametrize("name", GRAD)
+def test_render_gradients(name):
+    cfg, a = gu.load(name)
+    (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
+    rays = a["rays"].clone()
+    leaves = {}
+    for tag, P in (("coarse", P_c), ("fine", P_f)):
+        if P is not None:
+            for n, p in P.items():
+                p.requires_grad_(True)
+                leaves[f"{tag}.{n}"] = p
+    for k in ("a_emb", "t_emb"):
+        if kw[k] is not None:
+            kw[k] = kw[k].clone().requires_grad_(True)
+            leaves[k] = kw[k]
+    if "grad.rays" in a:
+        rays.requires_grad_(True)
+        leaves["rays"] = rays
+    res = orc.render_rays(spec_c, P_c, spec_f, P_f, rays, **kw)
+    loss = sum(orc.nerfw_loss(res, a["target"]).values())
+    assert abs(loss.item() - a["loss"].item()) <= 1e-5 * max(1.0, abs(a["loss"].item()))
+    loss.backward()
+    checked = 0
+    for key, exp in a.items():
+        if key.startswith("grad.") and not key.startswith("grad.table_"):
+            g = leaves[key[5:]].grad
+            scale = max(exp.abs().max().item(), 1e-6)
+            assert (g - exp).abs().max().item() <= 2e-4 * scale + 1e-7, key
+            checked += 1
+        elif key.startswith("gradrows."):
+            g = leaves[key[9:]].grad[:4]
+            scale = max(exp.abs().max().item(), 1e-6)
+            assert (g - exp).abs().max().item() <= 2e-4 * scale + 1e-7, key
+            checked += 1
+        elif key.startswith("gradnorm."):
+            g = leaves[key[9:]].grad
+            assert abs(g.norm().item() - exp.item()) <= 2e-4 * max(exp.item(), 1e-6) + 1e-7, key
+    if "grad.table_a" in a:   # scatter of the per-ray latent grads into the table
+        ts = a["ts"]
+        for k, dim in (("a", 48), ("t", 16)):
+            tab = torch.zeros(cfg["n_vocab"], dim).index_add_(0, ts, leaves[f"{k}_emb"].grad)
+            exp = a[f"grad.table_{k}"]
+            assert (tab - exp).abs().max().item() <= 2e-4 * exp.abs().max().item() + 1e-7
+    assert checked > 10
