@@ -1,0 +1,168 @@
+/*
+ * nerf_fl_amd.h -- C ABI of the MI355X-native NeRF-W ray renderer.
+ *
+ * This is the drop-in boundary for ONE path of nmerty/nerf-fl: everything that
+ * happens inside `render_rays` (reference models/rendering.py:49-289) and the
+ * field it evaluates (reference models/nerf.py:6-32, 81-212).  The reference
+ * has no FFI of its own (it is pure Python); these are the entry points a
+ * ctypes stub in the reference's models/rendering.py would bind (see
+ * INTEGRATION.md).  Conventions:
+ *
+ *   - plain pointers and sizes only; no torch / HIP types in the signatures
+ *     (`stream` is a hipStream_t passed as void*),
+ *   - every pointer named d_* is DEVICE memory owned by the caller,
+ *   - nothing here allocates, frees or synchronises; all work is enqueued on
+ *     `stream` (graph-capturable),
+ *   - every function returns NFL_OK (0) or a negative NFL_E* code;
+ *     nfl_strerror() names it.  The Python shim raises RuntimeError on != 0,
+ *     which mirrors the reference's "plain Python exception" convention
+ *     (SURVEY.md 8b).
+ */
+#ifndef NERF_FL_AMD_H
+#define NERF_FL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFL_ABI_VERSION 1
+
+enum {
+    NFL_OK = 0,
+    NFL_EINVAL = -1,      /* bad argument (null pointer, size, unsupported config) */
+    NFL_ELAUNCH = -2,     /* hipLaunchKernel / hipMemcpyAsync failed             */
+    NFL_ENODEV = -3,      /* no gfx950 device / kernel image not loadable         */
+    NFL_ESMALL = -4       /* caller-provided buffer too small                     */
+};
+
+/* Arithmetic used inside the MLP (everything outside the matrix products --
+ * positional encoding, activations, compositing, sampling -- is always fp32). */
+enum {
+    NFL_PREC_F16X3 = 0,   /* fp16 MFMA, operands split hi+lo, 3 products: ~2^-21 relative, fp32-class (default) */
+    NFL_PREC_F16   = 1    /* fp16 MFMA, single product: ~2^-11 relative (fast mode)                               */
+};
+
+/* One field (reference class NeRF, models/nerf.py:80-151).  W=256, D=8,
+ * skips=[4] are fixed, as in every configuration the reference ships. */
+typedef struct nfl_field_desc {
+    int32_t n_emb_xyz;          /* PosEmbedding freqs for xyz: 10 or 15 (opt.py:25; test_phototourism.ipynb) */
+    int32_t n_emb_dir;          /* must be 4 (opt.py:27)                                                       */
+    int32_t encode_appearance;  /* NeRF-A head: dir layer sees n_a extra inputs (nerf.py:115,134)             */
+    int32_t n_a;                /* 48                                                                         */
+    int32_t encode_transient;   /* NeRF-U head (nerf.py:141-151)                                              */
+    int32_t n_tau;              /* 16                                                                         */
+    float   beta_min;           /* added after compositing (rendering.py:185)                                 */
+    int32_t reserved;
+} nfl_field_desc;
+
+/* Device pointers to the fp32 parameters of one field, `nn.Linear` layout
+ * (weight = (out,in) row-major, bias = (out)); index with NFL_P_*.
+ * Names are the reference's state_dict keys. */
+enum {
+    NFL_P_XYZ1 = 0,  /* xyz_encoding_1.0 ... xyz_encoding_8.0 = NFL_P_XYZ1 + i */
+    NFL_P_FINAL = 8, /* xyz_encoding_final      */
+    NFL_P_DIR = 9,   /* dir_encoding.0          */
+    NFL_P_SIGMA = 10,/* static_sigma.0          */
+    NFL_P_RGB = 11,  /* static_rgb.0            */
+    NFL_P_T0 = 12,   /* transient_encoding.0, .2, .4, .6 = NFL_P_T0 + j */
+    NFL_P_TSIGMA = 16,
+    NFL_P_TRGB = 17,
+    NFL_P_TBETA = 18,
+    NFL_NUM_LAYERS = 19
+};
+typedef struct nfl_field_params {
+    const float* weight[NFL_NUM_LAYERS];
+    const float* bias[NFL_NUM_LAYERS];
+} nfl_field_params;
+
+/* ---- plan: static tables describing the packed weight stream ------------ */
+
+/* Bytes of the (host-built, then caller-uploaded) plan for this field. */
+size_t nfl_plan_bytes(const nfl_field_desc* desc);
+/* Fill `h_plan` (host memory, nfl_plan_bytes) for `prec`.  The caller copies it
+ * verbatim to device memory and passes that pointer as d_plan below. */
+int nfl_plan_build(const nfl_field_desc* desc, int prec, void* h_plan, size_t bytes);
+/* Bytes of the packed weight stream (fp16 MFMA fragments + fp32 bias table). */
+size_t nfl_packed_bytes(const nfl_field_desc* desc, int prec);
+/* Number of fp32 parameters of the field (sum of numel), for gradient arenas. */
+size_t nfl_param_count(const nfl_field_desc* desc);
+
+/* Re-pack the current fp32 parameters into MFMA fragment order (run after every
+ * optimizer step; ~2.4 MB read, <=4.8 MB written). h_plan is the same table in
+ * HOST memory (used only to size the launch). */
+int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_params* params,
+                   void* d_packed, size_t packed_bytes, void* stream);
+
+/* ---- one rendering pass (reference: inference(), rendering.py:83-226) --- */
+
+typedef struct nfl_pass_args {
+    /* geometry */
+    const float* d_rays;        /* (R,8): o(3) d(3) near far   (rendering.py:231-233)  */
+    const float* d_view_dir;    /* (R,3) or NULL -> use rays_d (rendering.py:236-238)  */
+    int32_t n_rays;             /* R                                                     */
+    int32_t n_samples;          /* samples per ray in THIS pass: N_samples (coarse) or N_samples+N_importance (fine) */
+    /* depths: either given (fine pass: sorted output of nfl_sample_pdf) ...      */
+    const float* d_z;           /* (R,n_samples) or NULL                                 */
+    /* ... or generated in-kernel (coarse pass, rendering.py:243-259)              */
+    const float* d_lin;         /* (n_samples) = linspace(0,1,n_samples); required when d_z == NULL */
+    const float* d_perturb_rand;/* (R,n_samples) U[0,1) or NULL when perturb == 0         */
+    float   perturb;
+    int32_t use_disp;
+    float*  d_z_out;            /* (R,n_samples) or NULL: the depths actually used       */
+    /* density noise (rendering.py:151-152; ignored when the transient head is on) */
+    const float* d_noise;       /* (R,n_samples) N(0,1) or NULL                          */
+    float   noise_std;
+    /* latent codes, already looked up per ray (rendering.py:276-286)              */
+    const float* d_a_emb;       /* (R,n_a)  or NULL                                      */
+    const float* d_t_emb;       /* (R,n_tau) or NULL -> transient head off for this pass */
+    /* mode */
+    int32_t sigma_only;         /* coarse pass at test_time (rendering.py:103-111,169)   */
+    int32_t white_back;
+    int32_t test_extras;        /* test_time on a transient pass: rgb/depth_fine_{static,transient} */
+    int32_t reserved;
+    /* outputs (any may be NULL = not wanted) */
+    float* d_weights;           /* (R,n_samples)                                         */
+    float* d_opacity;           /* (R)                                                   */
+    float* d_rgb;               /* (R,3)  rgb_coarse / rgb_fine                          */
+    float* d_depth;             /* (R)                                                   */
+    float* d_transient_sigmas;  /* (R,n_samples)                                         */
+    float* d_beta;              /* (R)                                                   */
+    float* d_rgb_static;        /* (R,3)  _rgb_fine_static                               */
+    float* d_rgb_transient;     /* (R,3)  _rgb_fine_transient                            */
+    float* d_rgb_static_only;   /* (R,3)  rgb_fine_static   (test_extras)                */
+    float* d_depth_static_only; /* (R)    depth_fine_static                              */
+    float* d_rgb_transient_only;/* (R,3)  rgb_fine_transient                             */
+    float* d_depth_transient_only;/* (R)  depth_fine_transient                           */
+    float* d_field_raw;         /* (R*n_samples,9) raw field outputs [rgb,sigma,rgb_t,sigma_t,beta] or NULL (tests) */
+} nfl_pass_args;
+
+/* Evaluate the field on every sample of every ray and alpha-composite on the
+ * fly (one fused kernel; per-sample activations never reach HBM). */
+int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed,
+                    const nfl_pass_args* args, void* stream);
+
+/* ---- hierarchical sampling (reference sample_pdf, rendering.py:7-46, plus the
+ * concat + sort of rendering.py:267-272) -------------------------------------
+ * d_z_coarse (R,S), d_weights_coarse (R,S); d_u (R,I) or NULL with d_u_row (I)
+ * = linspace(0,1,I) shared by all rays (det).  Outputs: d_z_fine (R,S+I) sorted
+ * ascending; d_samples (R,I) unsorted draws or NULL. */
+int nfl_sample_pdf(const float* d_z_coarse, const float* d_weights_coarse,
+                   const float* d_u, const float* d_u_row,
+                   int32_t n_rays, int32_t n_samples, int32_t n_importance,
+                   float* d_z_fine, float* d_samples, void* stream);
+
+/* ---- misc ---------------------------------------------------------------- */
+int         nfl_abi_version(void);
+const char* nfl_version(void);        /* "nerf_fl_amd <x.y> gfx950 ..." */
+const char* nfl_strerror(int code);
+/* name of the dominant kernel of nfl_render_pass for (prec, n_emb_xyz), as it
+ * appears in rocprofv3 kernel traces (used by bench.py to pair profiles) */
+const char* nfl_render_kernel_name(int prec, int n_emb_xyz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_FL_AMD_H */

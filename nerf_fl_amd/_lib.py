@@ -1,0 +1,101 @@
+"""ctypes binding of libnerf_fl_amd.so (the C ABI in include/nerf_fl_amd.h).
+
+There is no fallback: if the shared library is missing or does not export the
+ABI this package was written against, importing a renderer entry point raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerf_fl_amd.so")
+
+NFL_ABI_VERSION = 1
+NFL_PREC_F16X3 = 0
+NFL_PREC_F16 = 1
+NFL_NUM_LAYERS = 19
+
+# layer slot -> state_dict prefix (reference models/nerf.py:121-151)
+LAYER_NAMES = (
+    [f"xyz_encoding_{i + 1}.0" for i in range(8)]
+    + ["xyz_encoding_final", "dir_encoding.0", "static_sigma.0", "static_rgb.0"]
+    + [f"transient_encoding.{j}" for j in (0, 2, 4, 6)]
+    + ["transient_sigma.0", "transient_rgb.0", "transient_beta.0"]
+)
+assert len(LAYER_NAMES) == NFL_NUM_LAYERS
+
+
+class FieldDesc(C.Structure):
+    _fields_ = [
+        ("n_emb_xyz", C.c_int32), ("n_emb_dir", C.c_int32),
+        ("encode_appearance", C.c_int32), ("n_a", C.c_int32),
+        ("encode_transient", C.c_int32), ("n_tau", C.c_int32),
+        ("beta_min", C.c_float), ("reserved", C.c_int32),
+    ]
+
+
+class FieldParams(C.Structure):
+    _fields_ = [("weight", C.c_void_p * NFL_NUM_LAYERS), ("bias", C.c_void_p * NFL_NUM_LAYERS)]
+
+
+class PassArgs(C.Structure):
+    _fields_ = [
+        ("d_rays", C.c_void_p), ("d_view_dir", C.c_void_p),
+        ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+        ("d_z", C.c_void_p), ("d_lin", C.c_void_p), ("d_perturb_rand", C.c_void_p),
+        ("perturb", C.c_float), ("use_disp", C.c_int32),
+        ("d_z_out", C.c_void_p),
+        ("d_noise", C.c_void_p), ("noise_std", C.c_float),
+        ("d_a_emb", C.c_void_p), ("d_t_emb", C.c_void_p),
+        ("sigma_only", C.c_int32), ("white_back", C.c_int32),
+        ("test_extras", C.c_int32), ("reserved", C.c_int32),
+        ("d_weights", C.c_void_p), ("d_opacity", C.c_void_p), ("d_rgb", C.c_void_p), ("d_depth", C.c_void_p),
+        ("d_transient_sigmas", C.c_void_p), ("d_beta", C.c_void_p),
+        ("d_rgb_static", C.c_void_p), ("d_rgb_transient", C.c_void_p),
+        ("d_rgb_static_only", C.c_void_p), ("d_depth_static_only", C.c_void_p),
+        ("d_rgb_transient_only", C.c_void_p), ("d_depth_transient_only", C.c_void_p),
+        ("d_field_raw", C.c_void_p),
+    ]
+
+
+# every symbol include/nerf_fl_amd.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("nfl_plan_bytes", C.c_size_t, [C.POINTER(FieldDesc)]),
+    ("nfl_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int, C.c_void_p, C.c_size_t]),
+    ("nfl_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int]),
+    ("nfl_param_count", C.c_size_t, [C.POINTER(FieldDesc)]),
+    ("nfl_pack_field", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FieldParams), C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("nfl_render_pass", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassArgs), C.c_void_p]),
+    ("nfl_sample_pdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nfl_abi_version", C.c_int, []),
+    ("nfl_version", C.c_char_p, []),
+    ("nfl_strerror", C.c_char_p, [C.c_int]),
+    ("nfl_render_kernel_name", C.c_char_p, [C.c_int, C.c_int]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"nerf_fl_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C nerf_fl_amd/csrc`. There is no CPU or eager-PyTorch fallback for render_rays.")
+    h = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(h, name)            # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if h.nfl_abi_version() != NFL_ABI_VERSION:
+        raise RuntimeError(f"nerf_fl_amd: ABI mismatch (library {h.nfl_abi_version()}, python {NFL_ABI_VERSION})")
+    _lib = h
+    return _lib
+
+
+def check(code, what):
+    if code != 0:
+        raise RuntimeError(f"nerf_fl_amd: {what} failed: {lib().nfl_strerror(code).decode()} ({code})")

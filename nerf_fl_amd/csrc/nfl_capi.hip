@@ -1,0 +1,70 @@
+// nfl_capi.hip -- the extern "C" surface declared in include/nerf_fl_amd.h.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include "../../include/nerf_fl_amd.h"
+#include "nfl_plan.h"
+
+extern "C" int nfl_launch_render_x3(const NflPlan*, const void*, const void*, const nfl_pass_args*, void*);
+extern "C" int nfl_launch_render_x1(const NflPlan*, const void*, const void*, const nfl_pass_args*, void*);
+
+extern "C" {
+
+size_t nfl_plan_bytes(const nfl_field_desc*) { return sizeof(NflPlan); }
+
+int nfl_plan_build(const nfl_field_desc* desc, int prec, void* h_plan, size_t bytes) {
+    if (!h_plan) return NFL_EINVAL;
+    if (bytes < sizeof(NflPlan)) return NFL_ESMALL;
+    return nfl_plan_fill(desc, prec, static_cast<NflPlan*>(h_plan));
+}
+
+size_t nfl_packed_bytes(const nfl_field_desc* desc, int prec) {
+    NflPlan p;
+    if (nfl_plan_fill(desc, prec, &p) != NFL_OK) return 0;
+    return (size_t)p.packed_bytes;
+}
+
+size_t nfl_param_count(const nfl_field_desc* d) {
+    if (!d) return 0;
+    const size_t cx = 6 * d->n_emb_xyz + 3, cd = 6 * d->n_emb_dir + 3, W = NFL_W, H = NFL_W / 2;
+    const size_t na = d->encode_appearance ? d->n_a : 0;
+    size_t n = (cx + 1) * W + 6 * (W + 1) * W + (W + cx + 1) * W;      // trunk
+    n += (W + 1) * W + (W + cd + na + 1) * H + (W + 1) + (H + 1) * 3;  // final, dir, sigma, rgb
+    if (d->encode_transient) n += (W + d->n_tau + 1) * H + 3 * (H + 1) * H + 5 * (H + 1);
+    return n;
+}
+
+int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed,
+                    const nfl_pass_args* a, void* stream) {
+    const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
+    if (!hp || hp->magic != NFL_PLAN_MAGIC || !d_plan || !d_packed || !a) return NFL_EINVAL;
+    if (a->n_rays < 0 || a->n_samples < 1 || !a->d_rays) return NFL_EINVAL;
+    if (!a->d_z && !a->d_lin) return NFL_EINVAL;
+    if (a->perturb > 0.f && !a->d_z && !a->d_perturb_rand) return NFL_EINVAL;
+    if (!a->sigma_only && hp->has_a && !a->d_a_emb) return NFL_EINVAL;
+    if (a->n_rays == 0) return NFL_OK;
+    if (hp->prec == NFL_PREC_F16X3) return nfl_launch_render_x3(hp, d_plan, d_packed, a, stream);
+    return nfl_launch_render_x1(hp, d_plan, d_packed, a, stream);
+}
+
+int nfl_abi_version(void) { return NFL_ABI_VERSION; }
+
+const char* nfl_version(void) { return "nerf_fl_amd 0.1 (gfx950, HIP; abi 1)"; }
+
+const char* nfl_strerror(int code) {
+    switch (code) {
+        case NFL_OK: return "ok";
+        case NFL_EINVAL: return "invalid argument or unsupported configuration";
+        case NFL_ELAUNCH: return "HIP launch failed";
+        case NFL_ENODEV: return "no usable gfx950 device";
+        case NFL_ESMALL: return "buffer too small";
+        default: return "unknown error";
+    }
+}
+
+const char* nfl_render_kernel_name(int prec, int n_emb_xyz) {
+    if (prec == NFL_PREC_F16X3) return n_emb_xyz == 15 ? "nfl_render_kernel<3, 1, 15>" : "nfl_render_kernel<3, 1, 10>";
+    return n_emb_xyz == 15 ? "nfl_render_kernel<1, 1, 15>" : "nfl_render_kernel<1, 1, 10>";
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// nfl_pack.hip -- repack fp32 nn.Linear parameters into the MFMA fragment stream.
+//
+// One wave (64 lanes) writes one k-step of one row tile: lane l = (h = l>>5,
+// i = l&31) gathers the 8 weights W[row(i)][col(ks, h, j)], j = 0..7, converts
+// them to fp16 (hi) and, in the 3-product mode, the fp16 residual (lo), and
+// stores 16 B (+16 B) at its lane-linear position.  Replaces nothing in the
+// reference (whose weights stay nn.Linear tensors, models/nerf.py:121-151); it is
+// the layout step that lets the render kernel read W with ds_read_b128 and no
+// swizzle.  HBM-bound and tiny: ~2.4 MB read, 1.2-2.4 MB written per field.
+#include <hip/hip_runtime.h>
+
+#include "../../include/nerf_fl_amd.h"
+#include "nfl_plan.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+struct PackArgs {
+    const NflPlan* plan;        // device copy
+    nfl_field_params params;
+    char* out;                  // packed buffer
+};
+
+__global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
+    const NflPlan& P = *a.plan;
+    const int lane = threadIdx.x;
+    const int gks = blockIdx.x;          // global k-step index in the stream
+    if (gks >= P.total_ks) {
+        // bias table: blocks total_ks .. total_ks + n_rt - 1, lanes 0..31
+        const int t = gks - P.total_ks;
+        if (t >= P.n_rt || lane >= 32) return;
+        const NflRowTile& rt = P.rt[t];
+        float v = 0.f;
+        for (int b = 0; b < rt.nblk; ++b) {
+            const int r = lane - rt.blk[b].dst_row;
+            if (r >= 0 && r < rt.blk[b].nrows) v = a.params.bias[rt.blk[b].layer][rt.blk[b].src_row0 + r];
+        }
+        reinterpret_cast<float*>(a.out + P.bias_off)[t * 32 + lane] = v;
+        return;
+    }
+    // locate the row tile containing this k-step (n_rt <= 112: linear scan is fine)
+    int t = 0;
+    while (t + 1 < P.n_rt && P.rt[t + 1].frag_off <= gks) ++t;
+    const NflRowTile& rt = P.rt[t];
+    int ks = gks - rt.frag_off;
+    int s = 0;
+    while (ks >= rt.seg[s].nks) { ks -= rt.seg[s].nks; ++s; }
+    const NflSeg seg = rt.seg[s];
+
+    const int i = lane & 31, h = lane >> 5;
+    const float* wrow = nullptr;
+    for (int b = 0; b < rt.nblk; ++b) {
+        const int r = i - rt.blk[b].dst_row;
+        if (r >= 0 && r < rt.blk[b].nrows) {
+            const int L = rt.blk[b].layer;
+            wrow = a.params.weight[L] + (size_t)(rt.blk[b].src_row0 + r) * P.ld[L];
+        }
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int m = seg.kind == NFL_SEG_ACT ? 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3)
+                                              : 16 * ks + 8 * h + j;
+        float w = 0.f;
+        if (wrow != nullptr && m < seg.ncols) w = wrow[seg.col0 + m];
+        const _Float16 wh = (_Float16)w;
+        hi[j] = wh;
+        lo[j] = (_Float16)(w - (float)wh);
+    }
+    char* dst = a.out + (size_t)gks * P.ks_bytes + lane * 16;
+    *reinterpret_cast<h8*>(dst) = hi;
+    if (P.nsplit == 3) *reinterpret_cast<h8*>(dst + 1024) = lo;
+}
+
+extern "C" int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_params* params,
+                              void* d_packed, size_t packed_bytes, void* stream) {
+    const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
+    if (!hp || !d_plan || !params || !d_packed || hp->magic != NFL_PLAN_MAGIC) return NFL_EINVAL;
+    if (packed_bytes < (size_t)hp->packed_bytes) return NFL_ESMALL;
+    PackArgs a;
+    a.plan = static_cast<const NflPlan*>(d_plan);
+    a.params = *params;
+    a.out = static_cast<char*>(d_packed);
+    hipLaunchKernelGGL(nfl_pack_kernel, dim3(hp->total_ks + hp->n_rt), dim3(64), 0,
+                       static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}

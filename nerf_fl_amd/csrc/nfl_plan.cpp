@@ -1,0 +1,146 @@
+// nfl_plan.cpp -- host-side builder of the packed-stream schedule (see nfl_plan.h).
+#include "nfl_plan.h"
+
+#include <string.h>
+
+#include "../../include/nerf_fl_amd.h"
+
+namespace {
+
+struct Builder {
+    NflPlan* p;
+    int ks_cursor = 0;
+    int chunk_ks = 0;     // k-steps in the currently open chunk
+    bool chunk_open = false;
+
+    void begin_chunk() {
+        p->chunk_off[p->n_chunks] = ks_cursor * p->ks_bytes;
+        p->n_chunks++;
+        chunk_ks = 0;
+        chunk_open = true;
+    }
+    void end_chunk() {
+        if (chunk_ks > p->max_chunk_ks) p->max_chunk_ks = chunk_ks;
+        chunk_open = false;
+    }
+    NflRowTile& add_tile() {
+        NflRowTile& t = p->rt[p->n_rt++];
+        memset(&t, 0, sizeof(t));
+        t.frag_off = ks_cursor;
+        return t;
+    }
+    void close_tile(NflRowTile& t) {
+        int n = 0;
+        for (int s = 0; s < t.nseg; ++s) n += t.seg[s].nks;
+        t.nks = n;
+        ks_cursor += n;
+        chunk_ks += n;
+    }
+    static void blk(NflRowTile& t, int layer, int nrows, int src_row0, int dst_row) {
+        NflBlk& b = t.blk[t.nblk++];
+        b.layer = (int16_t)layer; b.nrows = (int16_t)nrows; b.src_row0 = (int16_t)src_row0; b.dst_row = (int16_t)dst_row;
+    }
+    static void seg(NflRowTile& t, int nks, int kind, int col0, int ncols) {
+        NflSeg& s = t.seg[t.nseg++];
+        s.nks = (int16_t)nks; s.kind = (int16_t)kind; s.col0 = (int16_t)col0; s.ncols = (int16_t)ncols;
+    }
+    // a dense layer of `rows` outputs split into 32-row tiles, `tiles_per_chunk` tiles per chunk
+    template <class SegFn>
+    void layer(int layer_id, int rows, int tiles_per_chunk, SegFn segs) {
+        int ntile = (rows + 31) / 32;
+        for (int i = 0; i < ntile; ++i) {
+            if (i % tiles_per_chunk == 0) begin_chunk();
+            NflRowTile& t = add_tile();
+            int n = rows - 32 * i < 32 ? rows - 32 * i : 32;
+            blk(t, layer_id, n, 32 * i, 0);
+            segs(t);
+            close_tile(t);
+            if (i % tiles_per_chunk == tiles_per_chunk - 1 || i == ntile - 1) end_chunk();
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int nfl_plan_fill(const nfl_field_desc* d, int prec, NflPlan* p) {
+    if (!d || !p) return NFL_EINVAL;
+    if (d->n_emb_xyz != 10 && d->n_emb_xyz != 15) return NFL_EINVAL;
+    if (d->n_emb_dir != 4) return NFL_EINVAL;
+    if (prec != NFL_PREC_F16X3 && prec != NFL_PREC_F16) return NFL_EINVAL;
+    if (d->encode_appearance && d->n_a != 48) return NFL_EINVAL;
+    if (d->encode_transient && d->n_tau != 16) return NFL_EINVAL;
+
+    memset(p, 0, sizeof(*p));
+    p->magic = NFL_PLAN_MAGIC;
+    p->prec = prec;
+    p->nsplit = prec == NFL_PREC_F16X3 ? 3 : 1;
+    p->ks_bytes = prec == NFL_PREC_F16X3 ? 2048 : 1024;
+    p->n_emb_xyz = d->n_emb_xyz;
+    const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
+    p->nkp = (cx + 15) / 16;
+    p->has_a = d->encode_appearance ? 1 : 0;
+    p->has_t = d->encode_transient ? 1 : 0;
+    p->n_a = p->has_a ? d->n_a : 0;
+    p->n_tau = d->n_tau;
+    p->beta_min = d->beta_min;
+    const int W = NFL_W, H = NFL_W / 2, nkp = p->nkp;
+
+    for (int i = 0; i < 8; ++i) p->ld[NFL_P_XYZ1 + i] = i == 0 ? cx : (i == 4 ? W + cx : W);
+    p->ld[NFL_P_FINAL] = W;
+    p->ld[NFL_P_DIR] = W + cd + p->n_a;
+    p->ld[NFL_P_SIGMA] = W;
+    p->ld[NFL_P_RGB] = H;
+    p->ld[NFL_P_T0] = W + d->n_tau;
+    p->ld[NFL_P_T0 + 1] = p->ld[NFL_P_T0 + 2] = p->ld[NFL_P_T0 + 3] = H;
+    p->ld[NFL_P_TSIGMA] = p->ld[NFL_P_TRGB] = p->ld[NFL_P_TBETA] = H;
+
+    Builder b{p};
+    // trunk
+    b.layer(NFL_P_XYZ1 + 0, W, 2, [&](NflRowTile& t) { Builder::seg(t, nkp, NFL_SEG_NAT, 0, cx); });
+    for (int i = 1; i < 8; ++i) {
+        if (i == 4)
+            b.layer(NFL_P_XYZ1 + i, W, 1, [&](NflRowTile& t) {
+                Builder::seg(t, nkp, NFL_SEG_NAT, 0, cx);
+                Builder::seg(t, 16, NFL_SEG_ACT, cx, W);
+            });
+        else
+            b.layer(NFL_P_XYZ1 + i, W, 1, [&](NflRowTile& t) { Builder::seg(t, 16, NFL_SEG_ACT, 0, W); });
+    }
+    b.layer(NFL_P_SIGMA, 1, 1, [&](NflRowTile& t) { Builder::seg(t, 16, NFL_SEG_ACT, 0, W); });
+    p->n_rt_sigma = p->n_rt;
+    p->n_chunks_sigma = p->n_chunks;
+    // static head
+    b.layer(NFL_P_FINAL, W, 1, [&](NflRowTile& t) { Builder::seg(t, 16, NFL_SEG_ACT, 0, W); });
+    b.layer(NFL_P_DIR, H, 1, [&](NflRowTile& t) {
+        Builder::seg(t, 16, NFL_SEG_ACT, 0, W);
+        Builder::seg(t, 2, NFL_SEG_NAT, W, cd);
+        if (p->has_a) Builder::seg(t, 3, NFL_SEG_NAT, W + cd, p->n_a);
+    });
+    b.layer(NFL_P_RGB, 3, 1, [&](NflRowTile& t) { Builder::seg(t, 8, NFL_SEG_ACT, 0, H); });
+    p->n_rt_static = p->n_rt;
+    p->n_chunks_static = p->n_chunks;
+    // transient head
+    if (p->has_t) {
+        b.layer(NFL_P_T0, H, 1, [&](NflRowTile& t) {
+            Builder::seg(t, 16, NFL_SEG_ACT, 0, W);
+            Builder::seg(t, 1, NFL_SEG_NAT, W, d->n_tau);
+        });
+        for (int j = 1; j < 4; ++j)
+            b.layer(NFL_P_T0 + j, H, 2, [&](NflRowTile& t) { Builder::seg(t, 8, NFL_SEG_ACT, 0, H); });
+        b.begin_chunk();
+        NflRowTile& t = b.add_tile();
+        Builder::blk(t, NFL_P_TSIGMA, 1, 0, 0);
+        Builder::blk(t, NFL_P_TRGB, 3, 0, 1);
+        Builder::blk(t, NFL_P_TBETA, 1, 0, 8);
+        Builder::seg(t, 8, NFL_SEG_ACT, 0, H);
+        b.close_tile(t);
+        b.end_chunk();
+    }
+    p->total_ks = b.ks_cursor;
+    p->chunk_off[p->n_chunks] = p->total_ks * p->ks_bytes;
+    p->stream_bytes = p->total_ks * p->ks_bytes;
+    p->bias_off = p->stream_bytes;
+    p->packed_bytes = p->bias_off + p->n_rt * 32 * 4;
+    if (p->n_rt > NFL_MAX_RT || p->n_chunks > NFL_MAX_CHUNKS) return NFL_EINVAL;
+    return NFL_OK;
+}

@@ -1,0 +1,82 @@
+// nfl_plan.h -- the static schedule of one field's packed weight stream.
+//
+// The fused render kernel evaluates the MLP transposed, H^T[out, sample] =
+// W[out, in] * H^T[in, sample], one 32-row "row tile" of W at a time, with
+// v_mfma_f32_32x32x16_f16.  W is the A operand; it is pre-packed on the device
+// into MFMA fragment order ("frags": 64 lanes x 8 halves = 1 KiB; lane l holds
+// row l&31, k-slots 8*(l>>5)+j) in exactly the order the kernel consumes it, so
+// the kernel streams it global -> LDS -> registers with linear, conflict-free
+// accesses.  This header is shared by the host plan builder, the pack kernel
+// and the render kernel; the three must agree on the order below.
+//
+// Stream order (row tiles; "ks" = k-step of 16 input columns):
+//   L1      8 row tiles, K = P (encoded xyz, NKP ks)              -> X, relu
+//   L2..L4  8 row tiles each, K = 16 ks                           X->Y->X->Y
+//   L5      8 row tiles, K = P + Y (skip: encoded xyz FIRST)      -> X, relu
+//   L6..L8  8 row tiles each                                      X->Y->X->Y
+//   SIG     1 row tile (row 0 = static_sigma), K = Y              -> sigma
+//   ---- a sigma-only pass stops here ----
+//   FIN     8 row tiles (xyz_encoding_final, no activation), K=Y  -> X
+//   DIR     4 row tiles, K = X + D (dir PE 2 ks [+ appearance 3 ks]) -> Y[0:8], relu
+//   RGB     1 row tile (rows 0..2), K = Y[0:8]                    -> rgb
+//   ---- a pass without the transient head stops here ----
+//   T1      4 row tiles, K = X + tau (1 ks)                       -> Y[0:8], relu
+//   T2..T4  4 row tiles each, K = 8 ks               Y[0:8]->Y[8:16]->Y[0:8]->Y[8:16]
+//   THEAD   1 row tile (row 0 sigma_t, 1..3 rgb_t, 8 beta), K = Y[8:16]
+//
+// Chunks (the unit of the LDS ring; every chunk starts a new barrier epoch):
+//   L1: 2 row tiles per chunk; T2..T4: 2 row tiles per chunk; otherwise 1.
+#pragma once
+#include <stdint.h>
+
+#define NFL_PLAN_MAGIC 0x4e464c31u /* "NFL1" */
+#define NFL_W 256
+#define NFL_MAX_RT 112
+#define NFL_MAX_CHUNKS 104
+
+// k-slot -> input-column maps
+#define NFL_SEG_ACT 0   // produced by a previous row tile: k-slot (ks,h,j) <-> column 32*(ks>>1) + 16*(ks&1) + 8*(j>>2) + 4*h + (j&3)
+#define NFL_SEG_NAT 1   // built directly by the lanes:      k-slot (ks,h,j) <-> column 16*ks + 8*h + j
+
+struct NflBlk {      // rows [src_row0, src_row0+nrows) of layer `layer` land on tile rows dst_row..
+    int16_t layer, nrows, src_row0, dst_row;
+};
+struct NflSeg {      // `nks` k-steps reading columns col0 + map(k-slot), valid while map < ncols
+    int16_t nks, kind, col0, ncols;
+};
+struct NflRowTile {
+    int32_t frag_off;   // index of this tile's first k-step in the stream (units of k-steps)
+    int32_t nks;        // total k-steps
+    int32_t nblk, nseg;
+    NflBlk blk[3];
+    NflSeg seg[3];
+};
+
+struct NflPlan {
+    uint32_t magic;
+    int32_t prec, nsplit;         // nsplit = 1 or 3 products; frags carry (nsplit==3 ? hi+lo : hi)
+    int32_t n_emb_xyz, nkp;       // nkp = ceil((6*n_emb_xyz+3)/16)
+    int32_t has_a, has_t, n_a, n_tau;
+    int32_t n_rt, n_rt_sigma, n_rt_static;
+    int32_t n_chunks, n_chunks_sigma, n_chunks_static;
+    int32_t total_ks;             // k-steps in the whole stream
+    int32_t ks_bytes;             // bytes per k-step: 1024 (hi) or 2048 (hi+lo)
+    int32_t max_chunk_ks;         // largest chunk, in k-steps
+    int32_t stream_bytes;         // total_ks * ks_bytes
+    int32_t bias_off;             // byte offset of the fp32 bias table [n_rt][32] inside the packed buffer
+    int32_t packed_bytes;
+    float   beta_min;
+    int32_t ld[19];               // in_features of each layer (row stride of its weight)
+    int32_t chunk_off[NFL_MAX_CHUNKS + 1];   // byte offset of each chunk in the stream (+ end)
+    NflRowTile rt[NFL_MAX_RT];
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+struct nfl_field_desc;
+// returns 0 or a negative NFL_E* code
+int nfl_plan_fill(const struct nfl_field_desc* desc, int prec, struct NflPlan* plan);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,705 @@
+// nfl_render_impl.h -- the fused per-ray-chunk forward kernel.
+//
+// Replaces, for one pass (coarse or fine) of the reference's render_rays:
+//   models/rendering.py:243-261  depth generation + o + d*z
+//   models/nerf.py:19-32         positional encoding (in registers, never stored)
+//   models/rendering.py:98-139   the point-chunk loop and all repeat/cat glue
+//   models/nerf.py:153-212       the 8x256 MLP + heads   (MFMA, fp16 operands, fp32 accumulate)
+//   models/rendering.py:141-226  alpha compositing       (wave scans, fp32)
+//
+// Mapping onto CDNA4
+//   * workgroup = 4 waves, one per SIMD, up to 512 VGPR/AGPR each.  A workgroup owns a
+//     contiguous range of rays and walks their samples in "segments" of 32 samples
+//     (= one MFMA column block); a wave carries NCB segments at a time.
+//   * the MLP is evaluated transposed, H^T[out,sample] = W[out,in] . H^T[in,sample]
+//     with v_mfma_f32_32x32x16_f16.  Activations live in registers for the whole
+//     network: the 32x32 fp32 accumulator tile of one layer, converted to fp16, IS the
+//     B operand of the next layer (column = sample stays on the lane; the k-slot
+//     permutation this implies is folded into the packed weights, nfl_plan.h).
+//   * W streams global(L2) -> LDS through a 3-slot ring with global_load_lds (16 B per
+//     lane, lane-linear = exactly the fragment image), one raw s_barrier per chunk and
+//     a counted vmcnt so two chunks stay in flight across barriers; all four waves read
+//     every fragment with conflict-free ds_read_b128.
+//   * NSPLIT == 3: operands are split hi+lo in fp16 and three products are accumulated
+//     (w_lo*x_hi + w_hi*x_lo + w_hi*x_hi): ~2^-21 relative error per product instead of
+//     2^-11, at 3x the MFMA issue.  NSPLIT == 1 is the fast mode.
+//   * compositing: per segment, an exclusive product scan of (1-alpha) over 32 lanes
+//     gives the local transmittance; partial sums are linear in the incoming
+//     transmittance, so segments (and tiles) of one ray are folded through a tiny LDS
+//     record.  Nothing per-sample except the API's own (R,N) outputs is written.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "../../include/nerf_fl_amd.h"
+#include "nfl_plan.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+#define NFL_DEV __device__ __forceinline__
+
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+NFL_DEV void nfl_static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        nfl_static_for<I0 + 1, I1>(f);
+    }
+}
+#define NFL_NST 20            // floats in a segment / ray compositing record
+#define NFL_REC 32            // record stride (floats)
+
+struct RenderArgs {
+    const NflPlan* plan;      // device copy of the plan
+    const char* packed;       // fragment stream, then bias table at plan->bias_off
+    nfl_pass_args a;
+    int n_chunks;             // chunks per tile consumed by this pass (prefix of the stream)
+    int n_rt;                 // row tiles consumed by this pass
+    int bias_off;
+    int has_a;                // field has the appearance input
+    int use_t;                // transient head evaluated in this pass
+    int spr;                  // 32-sample segments per ray
+    int rays_per_wg;
+    float beta_min;
+};
+
+// ---------------------------------------------------------------------------------
+// small math
+// ---------------------------------------------------------------------------------
+NFL_DEV float nfl_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch default beta=1, threshold=20
+NFL_DEV float nfl_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// sin(2*pi*r) for r in about [-1, 2]; abs error < 2e-7 (minimax odd polynomial on [-1/4,1/4])
+NFL_DEV float nfl_sin_rev(float r) {
+    r = r - rintf(r);                                   // [-1/2, 1/2]
+    float a = fabsf(r);
+    a = a > 0.25f ? 0.5f - a : a;                       // sin(pi - t) = sin(t)
+    a = copysignf(a, r);
+    const float a2 = a * a;
+    float p = 3.953670604e+01f;
+    p = __builtin_fmaf(p, a2, -7.654978229e+01f);
+    p = __builtin_fmaf(p, a2, 8.160100407e+01f);
+    p = __builtin_fmaf(p, a2, -4.134165503e+01f);
+    p = __builtin_fmaf(p, a2, 6.283185160e+00f);
+    return a * p;
+}
+
+// x / (2*pi) as an unevaluated sum th + tl (exact to ~2^-45 relative)
+NFL_DEV void nfl_turns(float x, float& th, float& tl) {
+    const float C_HI = 0.15915493667125702f;            // fl32(1/(2 pi))
+    const float C_LO = 6.4206382432985265e-09f;         // 1/(2 pi) - C_HI
+    th = x * C_HI;
+    const float e = __builtin_fmaf(x, C_HI, -th);
+    tl = __builtin_fmaf(x, C_LO, e);
+}
+
+// feature f of [x | sin(2^0 x) | cos(2^0 x) | sin(2^1 x) ...] (3 columns per block);
+// f, N compile-time after unrolling, coordinates as turns (th, tl) + raw value
+template <int N>
+NFL_DEV float nfl_pe_feature(int f, const float (&raw)[3], const float (&th)[3], const float (&tl)[3]) {
+    if (f < 3) return raw[f];
+    if (f >= 6 * N + 3) return 0.f;
+    const int g = f - 3, k = g / 6, rem = g % 6, t = rem / 3, c = rem % 3;
+    const float sc = (float)(1 << k);
+    float r = __builtin_amdgcn_fractf(th[c] * sc) + tl[c] * sc;      // 2^k scaling is exact
+    if (t) r += 0.25f;                                                // cos(y) = sin(y + pi/2)
+    return nfl_sin_rev(r);
+}
+
+template <int NP>
+NFL_DEV void nfl_split8(const float (&v)[8], h8 (&dst)[NP]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 hi = (_Float16)v[j];
+        dst[0][j] = hi;
+        if (NP == 2) dst[1][j] = (_Float16)(v[j] - (float)hi);
+    }
+}
+
+// natural-order B operand of one k-step of a positional encoding: lane half h holds
+// features 16*ks + 8*h + j.  Both candidates are evaluated per-lane via selects so the
+// instruction stream is uniform.
+template <int N, int NP>
+NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th)[3], const float (&tl)[3],
+                          h8 (&dst)[NP]) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int f0 = 16 * ks + j, f1 = f0 + 8;
+        // select the feature descriptor by lane half, then evaluate once
+        if (f0 < 3 || f0 >= 6 * N + 3 || f1 >= 6 * N + 3) {
+            const float v0 = nfl_pe_feature<N>(f0, raw, th, tl);
+            const float v1 = nfl_pe_feature<N>(f1, raw, th, tl);
+            v[j] = h ? v1 : v0;
+        } else {
+            const int g0 = f0 - 3, g1 = f1 - 3;
+            const int k0 = g0 / 6, k1 = g1 / 6, t0 = (g0 % 6) / 3, t1 = (g1 % 6) / 3, c0 = g0 % 3, c1 = g1 % 3;
+            const float sc = h ? (float)(1 << k1) : (float)(1 << k0);
+            const float thc = h ? th[c1] : th[c0];
+            const float tlc = h ? tl[c1] : tl[c0];
+            const float ph = h ? 0.25f * t1 : 0.25f * t0;
+            const float r = __builtin_amdgcn_fractf(thc * sc) + tlc * sc + ph;
+            v[j] = nfl_sin_rev(r);
+        }
+    }
+    nfl_split8<NP>(v, dst);
+}
+
+// ---------------------------------------------------------------------------------
+// weight ring: global -> LDS by LDS-DMA, 3 slots, prefetch distance 2
+// ---------------------------------------------------------------------------------
+template <int SLOT_BYTES, int MAXP>
+struct NflRing {
+    const char* gsrc;
+    const int* chunk_off;
+    char* lds;          // ring base (LDS)
+    int n_chunks;
+    int c_issue;        // next chunk (index within the per-tile stream) to issue
+    int s_issue;        // slot it goes to
+    int s_read;         // slot of the next chunk to consume
+    int wave, lane;
+
+    NFL_DEV void issue() {
+        const int off0 = chunk_off[c_issue];
+        const int nbytes = chunk_off[c_issue + 1] - off0;
+        const char* src = gsrc + off0 + lane * 16;
+        char* dst = lds + s_issue * SLOT_BYTES;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            int byte = (wave + 4 * p) * 1024;
+            byte = byte < nbytes ? byte : nbytes - 1024;       // surplus pieces re-copy the last KiB
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + byte),
+                (__attribute__((address_space(3))) void*)(dst + byte), 16, 0, 0);
+        }
+        c_issue = c_issue + 1 == n_chunks ? 0 : c_issue + 1;
+        s_issue = s_issue == 2 ? 0 : s_issue + 1;
+    }
+    NFL_DEV void prime() {
+        issue();
+        issue();
+    }
+    // Wait for the oldest chunk in flight, make it visible to all waves, refill the slot
+    // that everybody has just finished reading, and return this lane's read base.
+    NFL_DEV const char* consume() {
+        // all but the MAXP youngest VMEM ops (= the younger chunk's pieces) are done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue();
+        const char* base = lds + s_read * SLOT_BYTES + lane * 16;
+        s_read = s_read == 2 ? 0 : s_read + 1;
+        return base;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// MFMA building blocks
+// ---------------------------------------------------------------------------------
+template <int NP, int NCB>
+NFL_DEV void nfl_bias_init(f16v (&acc)[NCB], const float* bias_rt, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f4v b = *reinterpret_cast<const f4v*>(bias_rt + 8 * q + 4 * h);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            acc[cb][4 * q + 0] = b[0];
+            acc[cb][4 * q + 1] = b[1];
+            acc[cb][4 * q + 2] = b[2];
+            acc[cb][4 * q + 3] = b[3];
+        }
+    }
+}
+
+// acc += W[frag0 .. frag0+NK) * in[ks0 .. ks0+NK)
+template <int NP, int NCB, int NK, int NIN>
+NFL_DEV void nfl_mma(f16v (&acc)[NCB], const h8 (&in)[NIN][NCB][NP], int ks0, const char* wl, int frag0) {
+    constexpr int KSB = 1024 * NP;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const h8 whi = *reinterpret_cast<const h8*>(wl + (frag0 + k) * KSB);
+        if (NP == 2) {
+            const h8 wlo = *reinterpret_cast<const h8*>(wl + (frag0 + k) * KSB + 1024);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, in[ks0 + k][cb][0], acc[cb], 0, 0, 0);
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, in[ks0 + k][cb][NP - 1], acc[cb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, in[ks0 + k][cb][0], acc[cb], 0, 0, 0);
+    }
+}
+
+// accumulator tile -> the two k-steps (2*tile, 2*tile+1) of the next layer's B operand
+template <int NP, int NCB, bool RELU, int NOUT>
+NFL_DEV void nfl_store_act(const f16v (&acc)[NCB], h8 (&out)[NOUT][NCB][NP], int ks) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = acc[cb][8 * s + j];
+                v[j] = RELU ? fmaxf(x, 0.f) : x;
+            }
+            nfl_split8<NP>(v, out[ks + s][cb]);
+        }
+}
+
+// A dense layer of NRT row tiles reading inA[ksA0..+NKA) then inB[ksB0..+NKB), TPC tiles per
+// ring chunk.  The epilogue of tile i-1 is issued after the MFMAs of tile i so the two overlap.
+template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, int NINA, int NINB, int NOUT, class Ring>
+NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
+                       const h8 (&inA)[NINA][NCB][NP], int ksA0,
+                       const h8 (&inB)[NINB][NCB][NP], int ksB0,
+                       h8 (&out)[NOUT][NCB][NP], int out_ks0) {
+    f16v acc[2][NCB];
+    const char* wl = nullptr;
+    nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        if (i % TPC == 0) wl = ring.consume();
+        constexpr int frag0 = (i % TPC) * (NKA + NKB);
+        nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
+        nfl_mma<NP, NCB, NKA, NINA>(acc[i & 1], inA, ksA0, wl, frag0);
+        if (NKB > 0) nfl_mma<NP, NCB, NKB, NINB>(acc[i & 1], inB, ksB0, wl, frag0 + NKA);
+        if (i > 0) nfl_store_act<NP, NCB, RELU, NOUT>(acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1));
+    });
+    nfl_store_act<NP, NCB, RELU, NOUT>(acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1));
+    rt += NRT;
+}
+
+// a single head tile (own chunk); the caller interprets the accumulator rows
+template <int NP, int NCB, int NK, int NIN, class Ring>
+NFL_DEV void nfl_head(Ring& ring, const float* bias_lds, int& rt, int h,
+                      const h8 (&in)[NIN][NCB][NP], int ks0, f16v (&acc)[NCB]) {
+    const char* wl = ring.consume();
+    nfl_bias_init<NP, NCB>(acc, bias_lds + rt * 32, h);
+    nfl_mma<NP, NCB, NK, NIN>(acc, in, ks0, wl, 0);
+    rt += 1;
+}
+
+// ---------------------------------------------------------------------------------
+// depths (reference models/rendering.py:243-259); every operation separately rounded
+// ---------------------------------------------------------------------------------
+NFL_DEV float nfl_z_plain(const nfl_pass_args& a, float near, float far, int i) {
+    const float s = a.d_lin[i];
+    const float oms = 1.0f - s;
+    if (!a.use_disp) return near * oms + far * s;
+    return 1.0f / (1.0f / near * oms + 1.0f / far * s);
+}
+NFL_DEV float nfl_z_at(const nfl_pass_args& a, int ray, float near, float far, int i) {
+    const int N = a.n_samples;
+    if (a.d_z) return a.d_z[(size_t)ray * N + i];
+    float z = nfl_z_plain(a, near, far, i);
+    if (a.perturb > 0.f) {
+        const float zm = nfl_z_plain(a, near, far, i > 0 ? i - 1 : 0);
+        const float zp = nfl_z_plain(a, near, far, i < N - 1 ? i + 1 : N - 1);
+        const float upper = i < N - 1 ? 0.5f * (z + zp) : z;
+        const float lower = i > 0 ? 0.5f * (zm + z) : z;
+        const float pr = a.perturb * a.d_perturb_rand[(size_t)ray * N + i];
+        z = lower + (upper - lower) * pr;
+    }
+    return z;
+}
+
+// 32-lane helpers (both halves of the wave run them independently)
+NFL_DEV float nfl_sum32(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------
+template <int NSPLIT, int NCB, int NFX>
+struct NflRenderCfg {
+    static constexpr int NP = NSPLIT == 3 ? 2 : 1;
+    static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
+    static constexpr int KSB = 1024 * NP;
+    static constexpr int MAXKS = 16 + (NKP > 5 ? NKP : 5);
+    static constexpr int SLOT = MAXKS * KSB;
+    static constexpr int MAXP = (SLOT + 4095) / 4096;
+    static constexpr int NSLOT = 4 * NCB;
+    static constexpr int LDS_RING = 3 * SLOT;
+    static constexpr int LDS_BIAS = NFL_MAX_RT * 32 * 4;
+    static constexpr int LDS_REC = (NSLOT + 2) * NFL_REC * 4;
+    static constexpr int LDS_CHK = (NFL_MAX_CHUNKS + 8) * 4;
+    static constexpr int LDS_BYTES = LDS_RING + LDS_BIAS + LDS_REC + LDS_CHK;
+};
+
+template <int NSPLIT, int NCB, int NFX>
+__global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) {
+    using C = NflRenderCfg<NSPLIT, NCB, NFX>;
+    constexpr int NP = C::NP, NKP = C::NKP, NSLOT = C::NSLOT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // small tables first (so ds_read immediates reach them from one base register), ring last
+    float* const bias_lds = reinterpret_cast<float*>(smem);
+    float* const rec_lds = reinterpret_cast<float*>(smem + C::LDS_BIAS);   // [NSLOT] segment records, then carry[2]
+    int* const chk_lds = reinterpret_cast<int*>(smem + C::LDS_BIAS + C::LDS_REC);
+
+    const nfl_pass_args& a = A.a;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int N = a.n_samples, SPR = A.spr;
+
+    const int ray0 = blockIdx.x * A.rays_per_wg;
+    int ray1 = ray0 + A.rays_per_wg;
+    if (ray1 > a.n_rays) ray1 = a.n_rays;
+    if (ray0 >= ray1) return;
+    const int seg_end = (ray1 - ray0) * SPR;
+    const int ntiles = (seg_end + NSLOT - 1) / NSLOT;
+
+    {   // bias table and chunk offsets -> LDS (LDS reads keep the VMEM queue free for the ring)
+        const float* bg = reinterpret_cast<const float*>(A.packed + A.bias_off);
+        for (int i = tid; i < A.n_rt * 32; i += 256) bias_lds[i] = bg[i];
+        for (int i = tid; i <= A.n_chunks; i += 256) chk_lds[i] = A.plan->chunk_off[i];
+    }
+    __syncthreads();
+
+    NflRing<C::SLOT, C::MAXP> ring;
+    ring.gsrc = A.packed;
+    ring.chunk_off = chk_lds;
+    ring.lds = smem + C::LDS_BIAS + C::LDS_REC + C::LDS_CHK;
+    ring.n_chunks = A.n_chunks;
+    ring.c_issue = 0;
+    ring.s_issue = 0;
+    ring.s_read = 0;
+    ring.wave = wave;
+    ring.lane = lane;
+    ring.prime();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        // ------------------------------------------------------------ per-sample setup
+        int s_ray[NCB], s_idx[NCB];
+        bool s_ok[NCB];
+        float s_z[NCB], s_dl[NCB];
+        h8 P[NKP][NCB][NP];
+        h8 X[16][NCB][NP], Y[16][NCB][NP];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int g = tile * NSLOT + wave * NCB + cb;        // segment index inside this workgroup
+            const bool seg_ok = g < seg_end;
+            const int gg = seg_ok ? g : seg_end - 1;
+            const int ray = ray0 + gg / SPR;
+            const int i = (gg % SPR) * 32 + c;
+            const bool ok = seg_ok && i < N;
+            const int ii = i < N ? i : N - 1;
+            const float* rp = a.d_rays + (size_t)ray * 8;
+            const f4v r0 = *reinterpret_cast<const f4v*>(rp);
+            const f4v r1 = *reinterpret_cast<const f4v*>(rp + 4);
+            const float near = r1[2], far = r1[3];
+            const float z = nfl_z_at(a, ray, near, far, ii);
+            const float zn = ii + 1 < N ? nfl_z_at(a, ray, near, far, ii + 1) : z;
+            s_ray[cb] = ray;
+            s_idx[cb] = ii;
+            s_ok[cb] = ok;
+            s_z[cb] = z;
+            s_dl[cb] = ii + 1 < N ? zn - z : 1e2f;
+            if (a.d_z_out && ok && h == 0) a.d_z_out[(size_t)ray * N + ii] = z;
+            float raw[3], th[3], tl[3];
+            raw[0] = r0[0] + r0[3] * z;
+            raw[1] = r0[1] + r1[0] * z;
+            raw[2] = r0[2] + r1[1] * z;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nfl_turns(raw[k], th[k], tl[k]);
+#pragma unroll
+            for (int ks = 0; ks < NKP; ++ks) {
+                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, P[ks][cb]);
+                __builtin_amdgcn_sched_barrier(0);      // bound the register pressure of the encoder
+            }
+        }
+
+        // ------------------------------------------------------------ the field
+        int rt = 0;
+        // raw head outputs of sample c (lane half 0); extracted at once so the 16-register
+        // accumulator tiles die immediately
+        float o_sig[NCB], o_rgb[NCB][3], o_tr[NCB][5];
+        nfl_dense<NP, NCB, NKP, 0, true, 8, 2>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0);       // L1
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L2
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0);        // L3
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L4
+        nfl_dense<NP, NCB, NKP, 16, true, 8, 1>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0);      // L5 (skip)
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L6
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0);        // L7
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L8
+        {
+            f16v hacc[NCB];
+            nfl_head<NP, NCB, 16>(ring, bias_lds, rt, h, Y, 0, hacc);                          // sigma
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) o_sig[cb] = hacc[cb][0];
+        }
+        if (!a.sigma_only) {
+            nfl_dense<NP, NCB, 16, 0, false, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0);   // final (linear)
+            {
+                h8 D[5][NCB][NP];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const float* dp = a.d_view_dir ? a.d_view_dir + (size_t)s_ray[cb] * 3
+                                                   : a.d_rays + (size_t)s_ray[cb] * 8 + 3;
+                    float raw[3], th[3], tl[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        raw[k] = dp[k];
+                        nfl_turns(raw[k], th[k], tl[k]);
+                    }
+                    nfl_pe_kstep<4, NP>(0, h, raw, th, tl, D[0][cb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, D[1][cb]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (A.has_a) {
+                        const float* ap = a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;
+#pragma unroll
+                        for (int ks = 0; ks < 3; ++ks) {
+                            const f4v v0 = *reinterpret_cast<const f4v*>(ap + 16 * ks);
+                            const f4v v1 = *reinterpret_cast<const f4v*>(ap + 16 * ks + 4);
+                            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            nfl_split8<NP>(v, D[2 + ks][cb]);
+                        }
+                    }
+                }
+                if (A.has_a)
+                    nfl_dense<NP, NCB, 16, 5, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0);
+                else
+                    nfl_dense<NP, NCB, 16, 2, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0);
+            }
+            {
+                f16v hacc[NCB];
+                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 0, hacc);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    o_rgb[cb][0] = hacc[cb][0];
+                    o_rgb[cb][1] = hacc[cb][1];
+                    o_rgb[cb][2] = hacc[cb][2];
+                }
+            }
+            if (A.use_t) {
+                h8 T[1][NCB][NP];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const float* tp = a.d_t_emb + (size_t)s_ray[cb] * 16 + 8 * h;
+                    const f4v v0 = *reinterpret_cast<const f4v*>(tp);
+                    const f4v v1 = *reinterpret_cast<const f4v*>(tp + 4);
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    nfl_split8<NP>(v, T[0][cb]);
+                }
+                nfl_dense<NP, NCB, 16, 1, true, 4, 1>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0);
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8);
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0);
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8);
+                f16v hacc[NCB];
+                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 8, hacc);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) o_tr[cb][k] = hacc[cb][k];     // row 8 (beta) = register 4
+                }
+            }
+        }
+
+        // ------------------------------------------------------------ compositing, phase 1
+        // (reference models/rendering.py:141-226).  Lanes 0..31 of each half own sample c.
+        float w_loc[NCB], sig_t[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const bool ok = s_ok[cb];
+            const float z = s_z[cb], dl = s_dl[cb];
+            const size_t sidx = (size_t)s_ray[cb] * N + s_idx[cb];
+            const float sg = nfl_softplus(o_sig[cb]);
+            float cr = 0.f, cg = 0.f, cbl = 0.f, tr = 0.f, tg = 0.f, tb = 0.f, sgt = 0.f, bt = 0.f;
+            if (!a.sigma_only) {
+                cr = nfl_sigmoid(o_rgb[cb][0]);
+                cg = nfl_sigmoid(o_rgb[cb][1]);
+                cbl = nfl_sigmoid(o_rgb[cb][2]);
+            }
+            if (A.use_t) {
+                sgt = nfl_softplus(o_tr[cb][0]);
+                tr = nfl_sigmoid(o_tr[cb][1]);
+                tg = nfl_sigmoid(o_tr[cb][2]);
+                tb = nfl_sigmoid(o_tr[cb][3]);
+                bt = nfl_softplus(o_tr[cb][4]);
+            }
+            if (a.d_field_raw && ok && h == 0) {
+                float* fr = a.d_field_raw + sidx * 9;
+                fr[0] = cr; fr[1] = cg; fr[2] = cbl; fr[3] = sg;
+                fr[4] = tr; fr[5] = tg; fr[6] = tb; fr[7] = sgt; fr[8] = bt;
+            }
+            float alpha, a_s = 0.f, a_t = 0.f;
+            if (A.use_t) {
+                a_s = 1.f - expf(-dl * sg);
+                a_t = 1.f - expf(-dl * sgt);
+                alpha = 1.f - expf(-dl * (sg + sgt));
+            } else {
+                const float nz = a.d_noise ? a.d_noise[sidx] * a.noise_std : 0.f;
+                alpha = 1.f - expf(-dl * fmaxf(sg + nz, 0.f));
+            }
+            if (!ok) { alpha = 0.f; a_s = 0.f; a_t = 0.f; }
+            // exclusive product scans of (1 - alpha) over the 32 samples of the segment
+            float inc[3] = {1.f - alpha, 1.f - a_s, 1.f - a_t};
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float n = __shfl_up(inc[k], d, 32);
+                    if (c >= d) inc[k] *= n;
+                }
+            float exc[3], prod[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float e = __shfl_up(inc[k], 1, 32);
+                exc[k] = c == 0 ? 1.f : e;
+                prod[k] = __shfl(inc[k], 31, 32);
+            }
+            const float w = alpha * exc[0];
+            w_loc[cb] = w;
+            sig_t[cb] = sgt;
+            float rec[NFL_NST];
+            rec[0] = prod[0]; rec[1] = prod[1]; rec[2] = prod[2];
+            rec[3] = nfl_sum32(w);
+            rec[11] = nfl_sum32(w * z);
+            if (A.use_t) {
+                const float ws = a_s * exc[0], wt = a_t * exc[0];
+                rec[4] = nfl_sum32(ws * cr); rec[5] = nfl_sum32(ws * cg); rec[6] = nfl_sum32(ws * cbl);
+                rec[7] = nfl_sum32(wt * tr); rec[8] = nfl_sum32(wt * tg); rec[9] = nfl_sum32(wt * tb);
+                rec[10] = nfl_sum32(wt * bt);
+                if (a.test_extras) {
+                    const float ws1 = a_s * exc[1], wt1 = a_t * exc[2];
+                    rec[12] = nfl_sum32(ws1 * cr); rec[13] = nfl_sum32(ws1 * cg); rec[14] = nfl_sum32(ws1 * cbl);
+                    rec[15] = nfl_sum32(ws1 * z);
+                    rec[16] = nfl_sum32(wt1 * tr); rec[17] = nfl_sum32(wt1 * tg); rec[18] = nfl_sum32(wt1 * tb);
+                    rec[19] = nfl_sum32(wt1 * z);
+                } else {
+#pragma unroll
+                    for (int k = 12; k < NFL_NST; ++k) rec[k] = 0.f;
+                }
+            } else {
+                rec[4] = nfl_sum32(w * cr); rec[5] = nfl_sum32(w * cg); rec[6] = nfl_sum32(w * cbl);
+#pragma unroll
+                for (int k = 7; k < NFL_NST; ++k) if (k != 11) rec[k] = 0.f;
+            }
+            if (lane == 0) {
+                float* dst = rec_lds + (wave * NCB + cb) * NFL_REC;
+#pragma unroll
+                for (int k = 0; k < NFL_NST; ++k) dst[k] = rec[k];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        // ------------------------------------------------------------ compositing, phase 2
+        // fold the segments of each ray in order; lane k (< NFL_NST) carries record entry k
+        const float* carry_in = rec_lds + (NSLOT + (tile & 1)) * NFL_REC;
+        float* carry_out = rec_lds + (NSLOT + ((tile + 1) & 1)) * NFL_REC;
+        const int kk = lane < NFL_NST ? lane : 0;
+        const int chain = kk < 3 ? kk : (kk < 12 ? 0 : (kk < 16 ? 1 : 2));
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int m = wave * NCB + cb;
+            const int g = tile * NSLOT + m;
+            if (g >= seg_end) continue;                         // wave-uniform
+            const int q = g % SPR, ray = ray0 + g / SPR;
+            int m0 = m - q;
+            float t_in = 1.f;        // transmittance (chain 0) entering my segment: every lane
+            float t_run = 1.f;       // running product of my chain
+            float acc = 0.f;
+            if (m0 < 0) {
+                t_in = carry_in[0];
+                t_run = carry_in[chain];
+                acc = kk < 3 ? 0.f : carry_in[kk];
+                m0 = 0;
+            }
+            for (int mm = m0; mm <= m; ++mm) {
+                const float* r = rec_lds + mm * NFL_REC;
+                if (mm < m) t_in *= r[0];
+                acc += t_run * r[kk];
+                t_run *= r[chain];
+            }
+            // per-sample outputs
+            if (s_ok[cb] && h == 0) {
+                const size_t sidx = (size_t)ray * N + s_idx[cb];
+                if (a.d_weights) a.d_weights[sidx] = w_loc[cb] * t_in;
+                if (A.use_t && a.d_transient_sigmas) a.d_transient_sigmas[sidx] = sig_t[cb];
+            }
+            if (q == SPR - 1) {
+                // ray complete: lane k holds the composited quantity k
+                const float wsum = __shfl(acc, 3);
+                const float white = a.white_back ? 1.f - wsum : 0.f;
+                const float stat = acc + white;                  // meaningful on lanes 4..6 and 12..14
+                const float tran = __shfl(acc, (lane + 3) & 63); // lanes 4..6 read 7..9
+                if (lane == 3 && a.d_opacity) a.d_opacity[ray] = acc;
+                if (lane == 11 && a.d_depth) a.d_depth[ray] = acc;
+                if (lane >= 4 && lane < 7) {
+                    if (A.use_t) {
+                        if (a.d_rgb_static) a.d_rgb_static[ray * 3 + lane - 4] = stat;
+                        if (a.d_rgb_transient) a.d_rgb_transient[ray * 3 + lane - 4] = tran;
+                        if (a.d_rgb) a.d_rgb[ray * 3 + lane - 4] = stat + tran;
+                    } else if (a.d_rgb) {
+                        a.d_rgb[ray * 3 + lane - 4] = stat;
+                    }
+                }
+                if (A.use_t) {
+                    if (lane == 10 && a.d_beta) a.d_beta[ray] = acc + A.beta_min;
+                    if (a.test_extras) {
+                        if (lane >= 12 && lane < 15 && a.d_rgb_static_only) a.d_rgb_static_only[ray * 3 + lane - 12] = stat;
+                        if (lane == 15 && a.d_depth_static_only) a.d_depth_static_only[ray] = acc;
+                        if (lane >= 16 && lane < 19 && a.d_rgb_transient_only) a.d_rgb_transient_only[ray * 3 + lane - 16] = acc;
+                        if (lane == 19 && a.d_depth_transient_only) a.d_depth_transient_only[ray] = acc;
+                    }
+                }
+            } else if (m == NSLOT - 1) {
+                // the ray continues in the next tile: hand its state over
+                if (lane < NFL_NST) carry_out[lane] = lane < 3 ? t_run : acc;
+            }
+        }
+        // the next tile's first consume() barrier orders these LDS reads/writes
+        // against the next phase-1 record writes (>= 70 barriers away).
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two prefetched chunks before exit
+}
+
+template <int NSPLIT, int NCB, int NFX>
+static int nfl_launch_render(const NflPlan* hp, const void* d_plan, const void* d_packed,
+                             const nfl_pass_args* args, hipStream_t stream) {
+    using C = NflRenderCfg<NSPLIT, NCB, NFX>;
+    RenderArgs A;
+    A.plan = static_cast<const NflPlan*>(d_plan);
+    A.packed = static_cast<const char*>(d_packed);
+    A.a = *args;
+    A.has_a = hp->has_a;
+    A.use_t = (hp->has_t && args->d_t_emb != nullptr && !args->sigma_only) ? 1 : 0;
+    A.n_chunks = args->sigma_only ? hp->n_chunks_sigma : (A.use_t ? hp->n_chunks : hp->n_chunks_static);
+    A.n_rt = args->sigma_only ? hp->n_rt_sigma : (A.use_t ? hp->n_rt : hp->n_rt_static);
+    A.bias_off = hp->bias_off;
+    A.spr = (args->n_samples + 31) / 32;
+    A.beta_min = hp->beta_min;
+    // contiguous ray ranges, one workgroup per CU where there is enough work
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    }
+    int rpw = (args->n_rays + ncu - 1) / ncu;
+    // keep whole tiles per workgroup where possible: rays per tile = NSLOT / spr (if >= 1)
+    const int rays_per_tile = C::NSLOT / A.spr;
+    if (rays_per_tile > 1) rpw = (rpw + rays_per_tile - 1) / rays_per_tile * rays_per_tile;
+    if (rpw < 1) rpw = 1;
+    A.rays_per_wg = rpw;
+    const int grid = (args->n_rays + rpw - 1) / rpw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_render_kernel<NSPLIT, NCB, NFX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+            return NFL_ENODEV;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((nfl_render_kernel<NSPLIT, NCB, NFX>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}

@@ -1,0 +1,92 @@
+"""Host-side mirror of the reference's field classes (models/nerf.py).
+
+`render_rays` never calls these modules' forward(): it reads their parameters
+(by the reference's state_dict names, so reference checkpoints load unchanged)
+and attributes (`typ`, `encode_appearance`, `encode_transient`, `beta_min`,
+`in_channels_*`, reference models/nerf.py:104-119) and evaluates the field inside
+the fused HIP kernel.  forward() is provided only so code that calls a module
+directly (reference models/nerf.py:153-212, 19-32) keeps working; it is plain
+PyTorch and not on the measured path.
+"""
+import torch
+from torch import nn
+
+
+class PosEmbedding(nn.Module):
+    """x -> [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(N-1) x), cos(2^(N-1) x)]
+    (reference models/nerf.py:6-32; log-spaced frequencies only)."""
+
+    def __init__(self, max_logscale, N_freqs, logscale=True):
+        super().__init__()
+        if not logscale:
+            raise NotImplementedError("linear frequency spacing is unused by the reference's configs")
+        if max_logscale != N_freqs - 1:
+            raise ValueError("frequencies must be 2^0 .. 2^(N_freqs-1)")
+        self.N_freqs = N_freqs
+        self.freqs = 2 ** torch.linspace(0, max_logscale, N_freqs)   # attribute, not a buffer (as in the reference)
+
+    def forward(self, x):
+        parts = [x]
+        for k in range(self.N_freqs):
+            y = x * float(2 ** k)
+            parts += [torch.sin(y), torch.cos(y)]
+        return torch.cat(parts, -1)
+
+
+class NeRF(nn.Module):
+    """Parameter container with the reference's layer names and shapes
+    (models/nerf.py:81-151): 8x256 trunk with the encoded position re-read at
+    layer 5, sigma / rgb heads, optional appearance input and transient head."""
+
+    def __init__(self, typ, D=8, W=256, skips=(4,), in_channels_xyz=63, in_channels_dir=27,
+                 encode_appearance=False, in_channels_a=48, encode_transient=False, in_channels_t=16,
+                 beta_min=0.03, refine_pose=False):
+        super().__init__()
+        if D != 8 or W != 256 or tuple(skips) != (4,):
+            raise NotImplementedError("the HIP renderer is built for D=8, W=256, skips=[4]")
+        if refine_pose:
+            raise NotImplementedError("BARF-weighted encoding (--refine_pose) is not built yet")
+        self.typ, self.D, self.W, self.skips = typ, D, W, list(skips)
+        self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
+        self.refine_pose = False
+        self.encode_appearance = False if typ == "coarse" else encode_appearance
+        self.in_channels_a = in_channels_a if encode_appearance else 0
+        self.encode_transient = False if typ == "coarse" else encode_transient
+        self.in_channels_t = in_channels_t
+        self.beta_min = beta_min
+
+        for i in range(D):
+            fan_in = in_channels_xyz if i == 0 else (W + in_channels_xyz if i in self.skips else W)
+            setattr(self, f"xyz_encoding_{i + 1}", nn.Sequential(nn.Linear(fan_in, W), nn.ReLU(True)))
+        self.xyz_encoding_final = nn.Linear(W, W)
+        self.dir_encoding = nn.Sequential(nn.Linear(W + in_channels_dir + self.in_channels_a, W // 2), nn.ReLU(True))
+        self.static_sigma = nn.Sequential(nn.Linear(W, 1), nn.Softplus())
+        self.static_rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
+        if self.encode_transient:
+            self.transient_encoding = nn.Sequential(
+                nn.Linear(W + in_channels_t, W // 2), nn.ReLU(True),
+                nn.Linear(W // 2, W // 2), nn.ReLU(True),
+                nn.Linear(W // 2, W // 2), nn.ReLU(True),
+                nn.Linear(W // 2, W // 2), nn.ReLU(True))
+            self.transient_sigma = nn.Sequential(nn.Linear(W // 2, 1), nn.Softplus())
+            self.transient_rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
+            self.transient_beta = nn.Sequential(nn.Linear(W // 2, 1), nn.Softplus())
+
+    def forward(self, x, sigma_only=False, output_transient=True):
+        cx, cda = self.in_channels_xyz, self.in_channels_dir + self.in_channels_a
+        xyz = x[:, :cx]
+        h = xyz
+        for i in range(self.D):
+            if i in self.skips:
+                h = torch.cat([xyz, h], 1)
+            h = getattr(self, f"xyz_encoding_{i + 1}")(h)
+        sigma = self.static_sigma(h)
+        if sigma_only:
+            return sigma
+        feat = self.xyz_encoding_final(h)
+        rgb = self.static_rgb(self.dir_encoding(torch.cat([feat, x[:, cx:cx + cda]], 1)))
+        out = [rgb, sigma]
+        if output_transient:
+            g = self.transient_encoding(torch.cat([feat, x[:, cx + cda:cx + cda + self.in_channels_t]], 1))
+            out += [self.transient_rgb(g), self.transient_sigma(g), self.transient_beta(g)]
+        return torch.cat(out, 1)
