@@ -1,0 +1,85 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol that
+include/nerf_fl_amd.h declares, and its host-only entry points (plan builder,
+size queries, argument validation) behave.  No kernel is launched."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from nerf_fl_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.lib()
+
+
+def test_header_symbols_exported(L):
+    hdr = open(os.path.join(ROOT, "include", "nerf_fl_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nfl_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_version_and_errors(L):
+    assert L.nfl_abi_version() == _lib.NFL_ABI_VERSION
+    assert b"gfx950" in L.nfl_version()
+    assert L.nfl_strerror(0) == b"ok"
+    assert L.nfl_strerror(-1) != L.nfl_strerror(-4)
+
+
+@pytest.mark.parametrize("nx,a,t,count", [(10, 0, 0, 595844), (10, 1, 1, 687113)])
+def test_param_count_matches_reference(L, nx, a, t, count):
+    # 595 844 (coarse / base fine), 687 113 (NeRF-W fine)
+    d = _lib.FieldDesc(nx, 4, a, 48, t, 16, 0.1, 0)
+    assert L.nfl_param_count(C.byref(d)) == count
+
+
+def test_plan_structure(L):
+    import numpy as np
+    d = _lib.FieldDesc(10, 4, 1, 48, 1, 16, 0.1, 0)
+    n = L.nfl_plan_bytes(C.byref(d))
+    buf = C.create_string_buffer(n)
+    assert L.nfl_plan_build(C.byref(d), _lib.NFL_PREC_F16X3, buf, n) == 0
+    assert L.nfl_plan_build(C.byref(d), _lib.NFL_PREC_F16X3, buf, 16) == -4          # NFL_ESMALL
+    hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
+    magic, prec, nsplit, nx, nkp, has_a, has_t = hdr[:7]
+    assert magic == 0x4E464C31 and nsplit == 3 and nx == 10 and nkp == 4 and has_a == 1 and has_t == 1
+    n_rt, n_rt_sigma, n_rt_static, n_chunks, n_chunks_sigma, n_chunks_static, total_ks, ks_bytes = hdr[9:17]
+    assert (n_rt_sigma, n_rt_static, n_rt) == (65, 78, 95)
+    assert (n_chunks_sigma, n_chunks_static, n_chunks) == (61, 74, 85)
+    assert ks_bytes == 2048
+    # k-steps: L1 8x4, six 256x256 layers 8x16, skip layer 8x20, sigma 16, final 8x16, dir 4x21, rgb 8,
+    # transient 4x17 + 3x(4x8) + 8
+    assert total_ks == 32 + 6 * 128 + 160 + 16 + 128 + 84 + 8 + 68 + 96 + 8
+    assert L.nfl_packed_bytes(C.byref(d), _lib.NFL_PREC_F16X3) == total_ks * 2048 + n_rt * 128
+    assert L.nfl_packed_bytes(C.byref(d), _lib.NFL_PREC_F16) == total_ks * 1024 + n_rt * 128
+
+
+def test_unsupported_configs_rejected(L):
+    for bad in (_lib.FieldDesc(12, 4, 0, 48, 0, 16, 0.1, 0), _lib.FieldDesc(10, 6, 0, 48, 0, 16, 0.1, 0),
+                _lib.FieldDesc(10, 4, 1, 32, 0, 16, 0.1, 0)):
+        n = L.nfl_plan_bytes(C.byref(bad))
+        buf = C.create_string_buffer(n)
+        assert L.nfl_plan_build(C.byref(bad), 0, buf, n) == -1
+    assert L.nfl_render_pass(None, None, None, None, None) == -1
+    assert L.nfl_sample_pdf(None, None, None, None, 1, 64, 64, None, None, None) == -1
+
+
+def test_render_rays_refuses_cpu_tensors():
+    import torch
+    from nerf_fl_amd import NeRF, PosEmbedding, render_rays
+    models = {"coarse": NeRF("coarse")}
+    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
+        render_rays(models, emb, torch.zeros(4, 8), torch.zeros(4, dtype=torch.long), 8)
