@@ -136,13 +136,75 @@ typedef struct nfl_pass_args {
     float* d_depth_static_only; /* (R)    depth_fine_static                              */
     float* d_rgb_transient_only;/* (R,3)  rgb_fine_transient                             */
     float* d_depth_transient_only;/* (R)  depth_fine_transient                           */
-    float* d_field_raw;         /* (R*n_samples,9) raw field outputs [rgb,sigma,rgb_t,sigma_t,beta] or NULL (tests) */
+    float* d_field_raw;         /* (R*n_samples,9) per-sample field outputs [rgb,sigma,rgb_t,sigma_t,beta] or NULL;
+                                   required (with d_act_stash) when a backward will follow                      */
+    char*  d_act_stash;         /* nfl_act_stash_bytes(): bf16 layer inputs of every sample, MFMA fragment order,
+                                   consumed by nfl_render_backward; NULL for inference                          */
 } nfl_pass_args;
 
 /* Evaluate the field on every sample of every ray and alpha-composite on the
  * fly (one fused kernel; per-sample activations never reach HBM). */
 int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed,
                     const nfl_pass_args* args, void* stream);
+
+/* ---- backward (training) ---------------------------------------------------
+ * The reference gets its gradients from autograd replaying ~100 ATen kernels per
+ * point chunk over saved (chunk,256) activations.  Here:
+ *   forward (d_act_stash, d_field_raw set)  ->  nfl_composite_backward  ->  nfl_mlp_dgrad
+ *   ->  nfl_mlp_wgrad.  All gradients are fp32; MLP products are bf16 MFMA with fp32
+ *   accumulation (dgrad: split operands, 3 products; wgrad: single product summed over
+ *   all samples). */
+size_t nfl_act_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples);
+size_t nfl_grad_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples);
+/* dgrad plan / packed stream (transposed weights, bf16 hi+lo); same calling pattern as
+ * nfl_plan_build / nfl_pack_field (pack with nfl_pack_field using these plans). */
+int    nfl_bwd_plan_build(const nfl_field_desc* desc, void* h_plan, size_t bytes);
+size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc);
+
+typedef struct nfl_compbwd_args {
+    const float* d_field_raw;       /* (R*N,9) from the forward pass                       */
+    const float* d_z;               /* (R,N) depths the forward pass used                  */
+    const float* d_noise;           /* (R,N) or NULL, as given to the forward pass         */
+    float   noise_std;
+    int32_t n_rays, n_samples;
+    int32_t use_transient;          /* the forward pass evaluated the transient head       */
+    int32_t white_back;
+    int32_t reserved;
+    /* gradients of the pass outputs; NULL = zero */
+    const float* g_weights;         /* (R,N)  */
+    const float* g_opacity;         /* (R)    */
+    const float* g_rgb;             /* (R,3)  rgb_coarse / rgb_fine                        */
+    const float* g_depth;           /* (R)    */
+    const float* g_transient_sigmas;/* (R,N)  */
+    const float* g_beta;            /* (R)    */
+    const float* g_rgb_static;      /* (R,3)  _rgb_fine_static                             */
+    const float* g_rgb_transient;   /* (R,3)  _rgb_fine_transient                          */
+    float* d_head_grads;            /* out (R*N,9): d/d pre-activation [rgb,sigma,rgb_t,sigma_t,beta] */
+} nfl_compbwd_args;
+int nfl_composite_backward(const nfl_compbwd_args* args, void* stream);
+
+typedef struct nfl_dgrad_args {
+    const float* d_head_grads;      /* (R*N,9) from nfl_composite_backward                 */
+    const char*  d_act_stash;       /* from the forward pass                               */
+    char*        d_grad_stash;      /* out, nfl_grad_stash_bytes()                         */
+    int32_t n_rays, n_samples;
+    int32_t use_transient;
+    int32_t reserved;
+    float* d_g_a_emb;               /* (R,n_a)  accumulated into (zero it first) or NULL   */
+    float* d_g_t_emb;               /* (R,n_tau) accumulated into (zero it first) or NULL  */
+} nfl_dgrad_args;
+int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
+                  const nfl_dgrad_args* args, void* stream);
+
+/* fp32 gradient tensors in nn.Linear layout, ACCUMULATED into (zero them first);
+ * entries may be NULL (layer absent / gradient not wanted). */
+typedef struct nfl_field_grads {
+    float* weight[NFL_NUM_LAYERS];
+    float* bias[NFL_NUM_LAYERS];
+} nfl_field_grads;
+int nfl_mlp_wgrad(const nfl_field_desc* desc, const char* d_act_stash, const char* d_grad_stash,
+                  int32_t n_rays, int32_t n_samples, int32_t use_transient,
+                  const nfl_field_grads* grads, void* stream);
 
 /* ---- hierarchical sampling (reference sample_pdf, rendering.py:7-46, plus the
  * concat + sort of rendering.py:267-272) -------------------------------------

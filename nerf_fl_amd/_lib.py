@@ -53,8 +53,31 @@ class PassArgs(C.Structure):
         ("d_rgb_static", C.c_void_p), ("d_rgb_transient", C.c_void_p),
         ("d_rgb_static_only", C.c_void_p), ("d_depth_static_only", C.c_void_p),
         ("d_rgb_transient_only", C.c_void_p), ("d_depth_transient_only", C.c_void_p),
-        ("d_field_raw", C.c_void_p),
+        ("d_field_raw", C.c_void_p), ("d_act_stash", C.c_void_p),
     ]
+
+
+class CompBwdArgs(C.Structure):
+    _fields_ = [
+        ("d_field_raw", C.c_void_p), ("d_z", C.c_void_p), ("d_noise", C.c_void_p), ("noise_std", C.c_float),
+        ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("use_transient", C.c_int32), ("white_back", C.c_int32),
+        ("reserved", C.c_int32),
+        ("g_weights", C.c_void_p), ("g_opacity", C.c_void_p), ("g_rgb", C.c_void_p), ("g_depth", C.c_void_p),
+        ("g_transient_sigmas", C.c_void_p), ("g_beta", C.c_void_p), ("g_rgb_static", C.c_void_p),
+        ("g_rgb_transient", C.c_void_p), ("d_head_grads", C.c_void_p),
+    ]
+
+
+class DgradArgs(C.Structure):
+    _fields_ = [
+        ("d_head_grads", C.c_void_p), ("d_act_stash", C.c_void_p), ("d_grad_stash", C.c_void_p),
+        ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("use_transient", C.c_int32), ("reserved", C.c_int32),
+        ("d_g_a_emb", C.c_void_p), ("d_g_t_emb", C.c_void_p),
+    ]
+
+
+class FieldGrads(C.Structure):
+    _fields_ = [("weight", C.c_void_p * NFL_NUM_LAYERS), ("bias", C.c_void_p * NFL_NUM_LAYERS)]
 
 
 # every symbol include/nerf_fl_amd.h declares: (name, restype, argtypes)
@@ -67,6 +90,14 @@ SYMBOLS = [
     ("nfl_render_pass", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassArgs), C.c_void_p]),
     ("nfl_sample_pdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nfl_act_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
+    ("nfl_grad_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
+    ("nfl_bwd_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_void_p, C.c_size_t]),
+    ("nfl_bwd_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc)]),
+    ("nfl_composite_backward", C.c_int, [C.POINTER(CompBwdArgs), C.c_void_p]),
+    ("nfl_mlp_dgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DgradArgs), C.c_void_p]),
+    ("nfl_mlp_wgrad", C.c_int, [C.POINTER(FieldDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                C.POINTER(FieldGrads), C.c_void_p]),
     ("nfl_abi_version", C.c_int, []),
     ("nfl_version", C.c_char_p, []),
     ("nfl_strerror", C.c_char_p, [C.c_int]),

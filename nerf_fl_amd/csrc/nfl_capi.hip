@@ -34,6 +34,29 @@ size_t nfl_param_count(const nfl_field_desc* d) {
     return n;
 }
 
+static size_t n_segments(int32_t n_rays, int32_t n_samples) {
+    return (size_t)n_rays * (size_t)((n_samples + 31) / 32);
+}
+size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples) {
+    if (!d || n_rays < 0 || n_samples < 1) return 0;
+    const int nkp = (6 * d->n_emb_xyz + 3 + 15) / 16;
+    return n_segments(n_rays, n_samples) * nfl_act_slots(nkp) * 1024 + 4096;      // + tail pad for 2-k-step tile reads
+}
+size_t nfl_grad_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples) {
+    if (!d || n_rays < 0 || n_samples < 1) return 0;
+    return n_segments(n_rays, n_samples) * NFL_GRD_SLOTS * 1024 + 4096;
+}
+int nfl_bwd_plan_build(const nfl_field_desc* desc, void* h_plan, size_t bytes) {
+    if (!h_plan) return NFL_EINVAL;
+    if (bytes < sizeof(NflPlan)) return NFL_ESMALL;
+    return nfl_plan_fill_bwd(desc, static_cast<NflPlan*>(h_plan));
+}
+size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc) {
+    NflPlan p;
+    if (nfl_plan_fill_bwd(desc, &p) != NFL_OK) return 0;
+    return (size_t)p.packed_bytes;
+}
+
 int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed,
                     const nfl_pass_args* a, void* stream) {
     const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
@@ -42,6 +65,7 @@ int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed
     if (!a->d_z && !a->d_lin) return NFL_EINVAL;
     if (a->perturb > 0.f && !a->d_z && !a->d_perturb_rand) return NFL_EINVAL;
     if (!a->sigma_only && hp->has_a && !a->d_a_emb) return NFL_EINVAL;
+    if (hp->is_bwd) return NFL_EINVAL;
     if (a->n_rays == 0) return NFL_OK;
     if (hp->prec == NFL_PREC_F16X3) return nfl_launch_render_x3(hp, d_plan, d_packed, a, stream);
     return nfl_launch_render_x1(hp, d_plan, d_packed, a, stream);

@@ -1,0 +1,309 @@
+// nfl_dgrad.hip -- fused backward of the field MLP w.r.t. its activations (dgrad).
+//
+// Hand-written replacement of what autograd replays for reference models/nerf.py:
+// 153-212: for every sample, walk the network from the heads back to layer 2,
+//   delta_{l-1} = (W_l^T delta_l) (.) [h_{l-1} > 0]
+// with the same register-resident transposed formulation as the forward kernel
+// (nfl_render_impl.h): delta^T[feature, sample] tiles are MFMA accumulators, converted
+// to bf16 hi+lo they are the B operand of the next product; W^T streams through the
+// LDS ring as pre-packed bf16 hi+lo fragments (3 products per algorithmic product).
+// The relu masks come from the forward pass' activation stash: the 2 KiB a wave needs
+// per row tile are DMA'd into the ring slot beside the weights, so the kernel issues no
+// ordinary global load inside the layer loop.  Every delta_l is written (bf16, fragment
+// order) to the gradient stash for the weight-gradient GEMMs (nfl_wgrad.hip).  The
+// appearance / transient latent gradients are the extra rows of W_dir^T / W_t0^T,
+// reduced over the samples of the ray with wave shuffles and accumulated with fp32 atomics.
+#include "nfl_render_impl.h"
+
+struct DgradArgs {
+    const NflPlan* plan;
+    const char* packed;
+    nfl_dgrad_args a;
+    int n_chunks, c_start;
+    int has_a, has_t, use_t;
+    int spr, rays_per_wg, nkp;
+};
+
+template <int NFX>
+struct NflDgradCfg {
+    static constexpr int NP = 2, NCB = 1;
+    static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
+    static constexpr int KSB = 2048;
+    static constexpr int MAXKS = 17;
+    static constexpr int WBYTES = MAXKS * KSB;
+    static constexpr int AUXB = 4 * 2048;
+    static constexpr int SLOT = WBYTES + AUXB;
+    static constexpr int MAXP = (WBYTES + 4095) / 4096;
+    static constexpr int LDS_TAB = 2 * (NFL_MAX_CHUNKS + 8) * 4;
+    static constexpr int LDS_BYTES = LDS_TAB + 3 * SLOT;
+};
+
+// ring with the per-wave mask pieces
+template <int SLOT_BYTES, int WBYTES, int MAXP>
+struct NflRingAux {
+    const char* gsrc;
+    const int* chunk_off;
+    const int* chunk_aux;
+    char* lds;
+    const char* aux_src;      // activation stash + lane*16
+    size_t seg_stride;        // bytes per segment record
+    int n_chunks, c_start, c_issue, s_issue, s_read;
+    int seg_issue, seg_last;  // this wave's (clamped) global segment for the tile c_issue belongs to
+    int wave, lane;
+
+    NFL_DEV void issue() {
+        const int off0 = chunk_off[c_issue];
+        const int nbytes = chunk_off[c_issue + 1] - off0;
+        const char* src = gsrc + off0 + lane * 16;
+        char* dst = lds + s_issue * SLOT_BYTES;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            int byte = (wave + 4 * p) * 1024;
+            byte = byte < nbytes ? byte : nbytes - 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + byte),
+                                             (__attribute__((address_space(3))) void*)(dst + byte), 16, 0, 0);
+        }
+        int slot = chunk_aux[c_issue];
+        slot = slot < 0 ? 0 : slot;
+        const char* ms = aux_src + (size_t)seg_issue * seg_stride + slot * 1024;
+        char* md = dst + WBYTES + wave * 2048;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ms,
+                                         (__attribute__((address_space(3))) void*)md, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ms + 1024),
+                                         (__attribute__((address_space(3))) void*)(md + 1024), 16, 0, 0);
+        if (c_issue + 1 == n_chunks) {
+            c_issue = c_start;
+            seg_issue = seg_issue + 4 < seg_last ? seg_issue + 4 : seg_last;
+        } else {
+            c_issue = c_issue + 1;
+        }
+        s_issue = s_issue == 2 ? 0 : s_issue + 1;
+    }
+    NFL_DEV const char* consume() {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue();
+        const char* base = lds + s_read * SLOT_BYTES + lane * 16;
+        s_read = s_read == 2 ? 0 : s_read + 1;
+        return base;
+    }
+};
+
+NFL_DEV void dg_zero(f16v (&acc)[1]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+}
+
+// accumulator tile -> masked, split, stored into the next operand set and the gradient stash
+template <bool MASK, int NOUT>
+NFL_DEV void dg_store(const f16v (&acc)[1], const b8 (&mk)[2], b8 (&out)[NOUT][1][2], int ks, char* gst, int slot) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = acc[0][8 * s + j];
+            v[j] = MASK ? ((float)mk[s][j] > 0.f ? x : 0.f) : x;
+        }
+        nfl_split8<2>(v, out[ks + s][0]);
+        if (gst) nfl_stash8(v, gst + (slot + s) * 1024);
+    }
+}
+
+// NRT transposed row tiles (one per chunk) with up to three K segments
+template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NA, int NB, int NC, int NOUT, class Ring>
+NFL_DEV void dg_tiles(Ring& ring, int wave,
+                      const b8 (&inA)[NA][1][2], int ksA, const b8 (&inB)[NB][1][2], int ksB,
+                      const b8 (&inC)[NC][1][2], int ksC,
+                      b8 (&out)[NOUT][1][2], int out_ks0, char* gst, int slot0) {
+    f16v acc[2][1];
+    b8 mk[2][2];
+    nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        const char* wl = ring.consume();
+        dg_zero(acc[i & 1]);
+        nfl_mma<2, 1, NKA, NA>(acc[i & 1], inA, ksA, wl, 0);
+        if (NKB > 0) nfl_mma<2, 1, NKB, NB>(acc[i & 1], inB, ksB, wl, NKA);
+        if (NKC > 0) nfl_mma<2, 1, NKC, NC>(acc[i & 1], inC, ksC, wl, NKA + NKB);
+        if (MASK) {
+            mk[i & 1][0] = *reinterpret_cast<const b8*>(wl + WB + wave * 2048);
+            mk[i & 1][1] = *reinterpret_cast<const b8*>(wl + WB + wave * 2048 + 1024);
+        }
+        if (i > 0) dg_store<MASK, NOUT>(acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1));
+    });
+    dg_store<MASK, NOUT>(acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1));
+}
+
+// one tile whose rows are latent inputs: sum over the 32 samples of the segment, add to the ray's gradient
+template <int NK, int NIN, class Ring>
+NFL_DEV void dg_latent_tile(Ring& ring, const b8 (&in)[NIN][1][2], int ks0, float* dst, int nvalid, int h, int c) {
+    const char* wl = ring.consume();
+    f16v acc[1];
+    dg_zero(acc);
+    nfl_mma<2, 1, NK, NIN>(acc, in, ks0, wl, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float s = nfl_sum32(acc[0][r]);
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (dst && c == 0 && row < nvalid) atomicAdd(dst + row, s);
+    }
+}
+
+template <int NFX>
+__global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
+    using C = NflDgradCfg<NFX>;
+    constexpr int NKP = C::NKP, WB = C::WBYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int* const chk_lds = reinterpret_cast<int*>(smem);
+    int* const aux_lds = chk_lds + NFL_MAX_CHUNKS + 8;
+    const nfl_dgrad_args& a = A.a;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const int N = a.n_samples, SPR = A.spr;
+
+    const int ray0 = blockIdx.x * A.rays_per_wg;
+    int ray1 = ray0 + A.rays_per_wg;
+    if (ray1 > a.n_rays) ray1 = a.n_rays;
+    if (ray0 >= ray1) return;
+    const int seg_end = (ray1 - ray0) * SPR;
+    const int ntiles = (seg_end + 3) / 4;
+
+    for (int i = tid; i <= A.n_chunks; i += 256) {
+        chk_lds[i] = A.plan->chunk_off[i];
+        aux_lds[i] = A.plan->chunk_aux[i];
+    }
+    __syncthreads();
+
+    NflRingAux<C::SLOT, C::WBYTES, C::MAXP> ring;
+    ring.gsrc = A.packed;
+    ring.chunk_off = chk_lds;
+    ring.chunk_aux = aux_lds;
+    ring.lds = smem + C::LDS_TAB;
+    ring.aux_src = a.d_act_stash + lane * 16;
+    ring.seg_stride = (size_t)nfl_act_slots(NKP) * 1024;
+    ring.n_chunks = A.n_chunks;
+    ring.c_start = A.c_start;
+    ring.c_issue = A.c_start;
+    ring.s_issue = 0;
+    ring.s_read = 0;
+    ring.seg_last = ray0 * SPR + seg_end - 1;
+    ring.seg_issue = ray0 * SPR + wave < ring.seg_last ? ray0 * SPR + wave : ring.seg_last;
+    ring.wave = wave;
+    ring.lane = lane;
+    ring.issue();
+    ring.issue();
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int g = tile * 4 + wave;
+        const bool seg_ok = g < seg_end;
+        const int gg = seg_ok ? g : seg_end - 1;
+        const int ray = ray0 + gg / SPR;
+        const int i = (gg % SPR) * 32 + c;
+        const bool ok = seg_ok && i < N;
+        char* gst = seg_ok ? a.d_grad_stash + (size_t)(ray0 * SPR + gg) * NFL_GRD_SLOTS * 1024 + lane * 16 : nullptr;
+
+        float hg[9];
+        {
+            const float* hp = a.d_head_grads + ((size_t)ray * N + (i < N ? i : N - 1)) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) hg[k] = (ok && h == 0) ? hp[k] : 0.f;
+        }
+        // head gradients as natural-order B operands (k = 8h + j)
+        b8 dS[1][1][2], dC[1][1][2], dTs[1][1][2], dTc[1][1][2], dTb[1][1][2];
+        {
+            const float vS[8] = {hg[3], 0, 0, 0, 0, 0, 0, 0};
+            const float vC[8] = {hg[0], hg[1], hg[2], 0, 0, 0, 0, 0};
+            const float vTs[8] = {hg[7], 0, 0, 0, 0, 0, 0, 0};
+            const float vTc[8] = {hg[4], hg[5], hg[6], 0, 0, 0, 0, 0};
+            const float vTb[8] = {hg[8], 0, 0, 0, 0, 0, 0, 0};
+            nfl_split8<2>(vS, dS[0][0]);
+            nfl_split8<2>(vC, dC[0][0]);
+            nfl_split8<2>(vTs, dTs[0][0]);
+            nfl_split8<2>(vTc, dTc[0][0]);
+            nfl_split8<2>(vTb, dTb[0][0]);
+            if (gst) {
+                nfl_stash8(vS, gst + (NFL_GRD_HEADS + 0) * 1024);
+                nfl_stash8(vC, gst + (NFL_GRD_HEADS + 1) * 1024);
+                nfl_stash8(vTs, gst + (NFL_GRD_HEADS + 2) * 1024);
+                nfl_stash8(vTc, gst + (NFL_GRD_HEADS + 3) * 1024);
+                nfl_stash8(vTb, gst + (NFL_GRD_HEADS + 4) * 1024);
+            }
+        }
+        b8 X[16][1][2], Y[16][1][2], Z[16][1][2];
+        if (A.use_t) {
+            dg_tiles<WB, true, 4, 1, 1, 1>(ring, wave, dTs, 0, dTc, 0, dTb, 0, Y, 0, gst, NFL_GRD_G(4));
+            dg_tiles<WB, true, 4, 8, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(3));
+            dg_tiles<WB, true, 4, 8, 0, 0>(ring, wave, Y, 8, Y, 0, Y, 0, Y, 0, gst, NFL_GRD_G(2));
+            dg_tiles<WB, true, 4, 8, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(1));
+            dg_latent_tile<8>(ring, Y, 8, (a.d_g_t_emb && seg_ok) ? a.d_g_t_emb + (size_t)ray * 16 : nullptr, 16, h, c);
+        }
+        dg_tiles<WB, true, 4, 1, 0, 0>(ring, wave, dC, 0, dC, 0, dC, 0, X, 0, gst, NFL_GRD_DIRH);
+        if (A.has_a) {
+            float* ga = (a.d_g_a_emb && seg_ok) ? a.d_g_a_emb + (size_t)ray * 48 : nullptr;
+            dg_latent_tile<8>(ring, X, 0, ga, 32, h, c);
+            dg_latent_tile<8>(ring, X, 0, ga ? ga + 32 : nullptr, 16, h, c);
+        }
+        if (A.use_t)
+            dg_tiles<WB, false, 8, 8, 8, 0>(ring, wave, X, 0, Y, 8, Y, 0, Z, 0, gst, NFL_GRD_FEAT);
+        else
+            dg_tiles<WB, false, 8, 8, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Z, 0, gst, NFL_GRD_FEAT);
+        dg_tiles<WB, true, 8, 16, 1, 0>(ring, wave, Z, 0, dS, 0, dS, 0, Y, 0, gst, NFL_GRD_D(8));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(7));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(6));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(5));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(4));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(3));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(2));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NFX>
+static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_packed, const nfl_dgrad_args* args,
+                        hipStream_t stream) {
+    using C = NflDgradCfg<NFX>;
+    DgradArgs A;
+    A.plan = static_cast<const NflPlan*>(d_plan);
+    A.packed = static_cast<const char*>(d_packed);
+    A.a = *args;
+    A.has_a = hp->has_a;
+    A.has_t = hp->has_t;
+    A.use_t = (hp->has_t && args->use_transient) ? 1 : 0;
+    A.n_chunks = hp->n_chunks;
+    A.c_start = (hp->has_t && !A.use_t) ? 17 : 0;
+    A.spr = (args->n_samples + 31) / 32;
+    A.nkp = hp->nkp;
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    int rpw = (args->n_rays + ncu - 1) / ncu;
+    const int rays_per_tile = 4 / A.spr;
+    if (rays_per_tile > 1) rpw = (rpw + rays_per_tile - 1) / rays_per_tile * rays_per_tile;
+    if (rpw < 1) rpw = 1;
+    A.rays_per_wg = rpw;
+    const int grid = (args->n_rays + rpw - 1) / rpw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_dgrad_kernel<NFX>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+            return NFL_ENODEV;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((nfl_dgrad_kernel<NFX>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}
+
+extern "C" int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
+                             const nfl_dgrad_args* args, void* stream) {
+    const NflPlan* hp = static_cast<const NflPlan*>(h_bwd_plan);
+    if (!hp || hp->magic != NFL_PLAN_MAGIC || !hp->is_bwd || !d_bwd_plan || !d_bwd_packed || !args) return NFL_EINVAL;
+    if (!args->d_head_grads || !args->d_act_stash || !args->d_grad_stash) return NFL_EINVAL;
+    if (args->n_rays < 0 || args->n_samples < 1) return NFL_EINVAL;
+    if (args->n_rays == 0) return NFL_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hp->n_emb_xyz == 10) return launch_dgrad<10>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->n_emb_xyz == 15) return launch_dgrad<15>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    return NFL_EINVAL;
+}

@@ -13,6 +13,7 @@
 #include "nfl_plan.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 
 struct PackArgs {
     const NflPlan* plan;        // device copy
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
         if (t >= P.n_rt || lane >= 32) return;
         const NflRowTile& rt = P.rt[t];
         float v = 0.f;
-        for (int b = 0; b < rt.nblk; ++b) {
+        for (int b = 0; b < (rt.trans ? 0 : rt.nblk); ++b) {
             const int r = lane - rt.blk[b].dst_row;
             if (r >= 0 && r < rt.blk[b].nrows) v = a.params.bias[rt.blk[b].layer][rt.blk[b].src_row0 + r];
         }
@@ -47,28 +48,52 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
     const NflSeg seg = rt.seg[s];
 
     const int i = lane & 31, h = lane >> 5;
-    const float* wrow = nullptr;
-    for (int b = 0; b < rt.nblk; ++b) {
-        const int r = i - rt.blk[b].dst_row;
-        if (r >= 0 && r < rt.blk[b].nrows) {
-            const int L = rt.blk[b].layer;
-            wrow = a.params.weight[L] + (size_t)(rt.blk[b].src_row0 + r) * P.ld[L];
+    const float* wrow = nullptr;      // forward tiles: the source row of this lane
+    const float* wcol = nullptr;      // dgrad tiles: the source column of this lane
+    int ldt = 0;
+    if (!rt.trans) {
+        for (int b = 0; b < rt.nblk; ++b) {
+            const int r = i - rt.blk[b].dst_row;
+            if (r >= 0 && r < rt.blk[b].nrows) {
+                const int L = rt.blk[b].layer;
+                wrow = a.params.weight[L] + (size_t)(rt.blk[b].src_row0 + r) * P.ld[L];
+            }
         }
+    } else if (i < rt.tncols) {
+        ldt = P.ld[seg.layer];
+        wcol = a.params.weight[seg.layer] + rt.tcol0 + i;
     }
-    h8 hi, lo;
+    float w[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int m = seg.kind == NFL_SEG_ACT ? 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3)
                                               : 16 * ks + 8 * h + j;
-        float w = 0.f;
-        if (wrow != nullptr && m < seg.ncols) w = wrow[seg.col0 + m];
-        const _Float16 wh = (_Float16)w;
-        hi[j] = wh;
-        lo[j] = (_Float16)(w - (float)wh);
+        w[j] = 0.f;
+        if (m < seg.ncols) {
+            if (wrow != nullptr) w[j] = wrow[seg.col0 + m];
+            if (wcol != nullptr) w[j] = wcol[(size_t)(seg.col0 + m) * ldt];
+        }
     }
     char* dst = a.out + (size_t)gks * P.ks_bytes + lane * 16;
-    *reinterpret_cast<h8*>(dst) = hi;
-    if (P.nsplit == 3) *reinterpret_cast<h8*>(dst + 1024) = lo;
+    if (P.elem == 0) {
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (_Float16)w[j];
+            lo[j] = (_Float16)(w[j] - (float)hi[j]);
+        }
+        *reinterpret_cast<h8*>(dst) = hi;
+        if (P.nsplit == 3) *reinterpret_cast<h8*>(dst + 1024) = lo;
+    } else {
+        b8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            hi[j] = (__bf16)w[j];
+            lo[j] = (__bf16)(w[j] - (float)hi[j]);
+        }
+        *reinterpret_cast<b8*>(dst) = hi;
+        if (P.nsplit == 3) *reinterpret_cast<b8*>(dst + 1024) = lo;
+    }
 }
 
 extern "C" int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_params* params,

@@ -40,9 +40,21 @@ struct Builder {
         NflBlk& b = t.blk[t.nblk++];
         b.layer = (int16_t)layer; b.nrows = (int16_t)nrows; b.src_row0 = (int16_t)src_row0; b.dst_row = (int16_t)dst_row;
     }
-    static void seg(NflRowTile& t, int nks, int kind, int col0, int ncols) {
+    static void seg(NflRowTile& t, int nks, int kind, int col0, int ncols, int layer = -1) {
         NflSeg& s = t.seg[t.nseg++];
         s.nks = (int16_t)nks; s.kind = (int16_t)kind; s.col0 = (int16_t)col0; s.ncols = (int16_t)ncols;
+        s.layer = (int16_t)layer;
+    }
+    // one transposed (dgrad) tile in its own chunk: rows = columns [tcol0, tcol0+tncols) of the sources
+    template <class SegFn>
+    void ttile(int tcol0, int tncols, int aux, SegFn segs) {
+        p->chunk_aux[p->n_chunks] = aux;
+        begin_chunk();
+        NflRowTile& t = add_tile();
+        t.trans = 1; t.tcol0 = (int16_t)tcol0; t.tncols = (int16_t)tncols;
+        segs(t);
+        close_tile(t);
+        end_chunk();
     }
     // a dense layer of `rows` outputs split into 32-row tiles, `tiles_per_chunk` tiles per chunk
     template <class SegFn>
@@ -62,14 +74,7 @@ struct Builder {
 
 }  // namespace
 
-extern "C" int nfl_plan_fill(const nfl_field_desc* d, int prec, NflPlan* p) {
-    if (!d || !p) return NFL_EINVAL;
-    if (d->n_emb_xyz != 10 && d->n_emb_xyz != 15) return NFL_EINVAL;
-    if (d->n_emb_dir != 4) return NFL_EINVAL;
-    if (prec != NFL_PREC_F16X3 && prec != NFL_PREC_F16) return NFL_EINVAL;
-    if (d->encode_appearance && d->n_a != 48) return NFL_EINVAL;
-    if (d->encode_transient && d->n_tau != 16) return NFL_EINVAL;
-
+static void common_init(const nfl_field_desc* d, int prec, NflPlan* p) {
     memset(p, 0, sizeof(*p));
     p->magic = NFL_PLAN_MAGIC;
     p->prec = prec;
@@ -83,8 +88,7 @@ extern "C" int nfl_plan_fill(const nfl_field_desc* d, int prec, NflPlan* p) {
     p->n_a = p->has_a ? d->n_a : 0;
     p->n_tau = d->n_tau;
     p->beta_min = d->beta_min;
-    const int W = NFL_W, H = NFL_W / 2, nkp = p->nkp;
-
+    const int W = NFL_W, H = NFL_W / 2;
     for (int i = 0; i < 8; ++i) p->ld[NFL_P_XYZ1 + i] = i == 0 ? cx : (i == 4 ? W + cx : W);
     p->ld[NFL_P_FINAL] = W;
     p->ld[NFL_P_DIR] = W + cd + p->n_a;
@@ -93,6 +97,80 @@ extern "C" int nfl_plan_fill(const nfl_field_desc* d, int prec, NflPlan* p) {
     p->ld[NFL_P_T0] = W + d->n_tau;
     p->ld[NFL_P_T0 + 1] = p->ld[NFL_P_T0 + 2] = p->ld[NFL_P_T0 + 3] = H;
     p->ld[NFL_P_TSIGMA] = p->ld[NFL_P_TRGB] = p->ld[NFL_P_TBETA] = H;
+    for (int i = 0; i <= NFL_MAX_CHUNKS; ++i) p->chunk_aux[i] = -1;
+}
+
+static int check_desc(const nfl_field_desc* d) {
+    if (!d) return NFL_EINVAL;
+    if (d->n_emb_xyz != 10 && d->n_emb_xyz != 15) return NFL_EINVAL;
+    if (d->n_emb_dir != 4) return NFL_EINVAL;
+    if (d->encode_appearance && d->n_a != 48) return NFL_EINVAL;
+    if (d->encode_transient && d->n_tau != 16) return NFL_EINVAL;
+    return NFL_OK;
+}
+
+// The dgrad stream (bf16, hi+lo): one transposed row tile per chunk, in the order the
+// backward kernel walks the network (heads first).  chunk_aux names the activation-stash
+// slot whose sign is the relu mask of that tile.
+extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, NflPlan* p) {
+    if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
+    common_init(d, NFL_PREC_F16X3, p);
+    p->elem = 1;
+    p->is_bwd = 1;
+    const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
+    const int W = NFL_W, H = NFL_W / 2, nkp = p->nkp;
+    Builder b{p};
+    if (p->has_t) {
+        for (int t = 0; t < 4; ++t)
+            b.ttile(32 * t, 32, nfl_act_g(nkp, 4) + 2 * t, [&](NflRowTile& r) {
+                Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TSIGMA);
+                Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_TRGB);
+                Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TBETA);
+            });
+        for (int j = 3; j >= 1; --j)
+            for (int t = 0; t < 4; ++t)
+                b.ttile(32 * t, 32, nfl_act_g(nkp, j) + 2 * t,
+                        [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0 + j); });
+        b.ttile(W, d->n_tau, -1, [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0); });
+    }
+    for (int t = 0; t < 4; ++t)
+        b.ttile(32 * t, 32, nfl_act_dirh(nkp) + 2 * t,
+                [&](NflRowTile& r) { Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_RGB); });
+    if (p->has_a)
+        for (int t = 0; t < 2; ++t)
+            b.ttile(W + cd + 32 * t, t == 0 ? 32 : p->n_a - 32, -1,
+                    [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR); });
+    for (int t = 0; t < 8; ++t)
+        b.ttile(32 * t, 32, -1, [&](NflRowTile& r) {
+            Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR);
+            if (p->has_t) Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0);
+        });
+    for (int t = 0; t < 8; ++t)
+        b.ttile(32 * t, 32, nfl_act_h(nkp, 8) + 2 * t, [&](NflRowTile& r) {
+            Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_FINAL);
+            Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_SIGMA);
+        });
+    for (int l = 8; l >= 2; --l)            // layer l (1-based) transposed -> gradient of h_{l-1}
+        for (int t = 0; t < 8; ++t)
+            b.ttile((l == 5 ? cx : 0) + 32 * t, 32, nfl_act_h(nkp, l - 1) + 2 * t,
+                    [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); });
+    p->n_rt_sigma = p->n_rt_static = p->n_rt;
+    p->n_chunks_sigma = p->n_chunks_static = p->n_chunks;
+    p->total_ks = b.ks_cursor;
+    p->chunk_off[p->n_chunks] = p->total_ks * p->ks_bytes;
+    p->stream_bytes = p->total_ks * p->ks_bytes;
+    p->bias_off = p->stream_bytes;
+    p->packed_bytes = p->bias_off + p->n_rt * 32 * 4;
+    if (p->n_rt > NFL_MAX_RT || p->n_chunks > NFL_MAX_CHUNKS) return NFL_EINVAL;
+    return NFL_OK;
+}
+
+extern "C" int nfl_plan_fill(const nfl_field_desc* d, int prec, NflPlan* p) {
+    if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
+    if (prec != NFL_PREC_F16X3 && prec != NFL_PREC_F16) return NFL_EINVAL;
+    common_init(d, prec, p);
+    const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
+    const int W = NFL_W, H = NFL_W / 2, nkp = p->nkp;
 
     Builder b{p};
     // trunk

@@ -41,13 +41,18 @@
 struct NflBlk {      // rows [src_row0, src_row0+nrows) of layer `layer` land on tile rows dst_row..
     int16_t layer, nrows, src_row0, dst_row;
 };
-struct NflSeg {      // `nks` k-steps reading columns col0 + map(k-slot), valid while map < ncols
+struct NflSeg {      // `nks` k-steps reading columns col0 + map(k-slot), valid while map < ncols.
+                     // Transposed tiles (dgrad streams): the k-slots run over ROWS col0 + map of `layer`.
     int16_t nks, kind, col0, ncols;
+    int16_t layer, pad0, pad1, pad2;
 };
 struct NflRowTile {
     int32_t frag_off;   // index of this tile's first k-step in the stream (units of k-steps)
     int32_t nks;        // total k-steps
     int32_t nblk, nseg;
+    // forward tiles (trans == 0): element(i, m) = W[blk(i).layer][blk.src_row0 + i - blk.dst_row][seg.col0 + m]
+    // dgrad tiles   (trans == 1): element(i, m) = W[seg.layer][seg.col0 + m][tcol0 + i]  (i < tncols), bias 0
+    int16_t trans, tcol0, tncols, pad;
     NflBlk blk[3];
     NflSeg seg[3];
 };
@@ -55,6 +60,8 @@ struct NflRowTile {
 struct NflPlan {
     uint32_t magic;
     int32_t prec, nsplit;         // nsplit = 1 or 3 products; frags carry (nsplit==3 ? hi+lo : hi)
+    int32_t elem;                 // 0: fp16 fragments (forward stream), 1: bf16 fragments (dgrad stream)
+    int32_t is_bwd;               // 1: this is the dgrad (transposed) stream
     int32_t n_emb_xyz, nkp;       // nkp = ceil((6*n_emb_xyz+3)/16)
     int32_t has_a, has_t, n_a, n_tau;
     int32_t n_rt, n_rt_sigma, n_rt_static;
@@ -68,8 +75,34 @@ struct NflPlan {
     float   beta_min;
     int32_t ld[19];               // in_features of each layer (row stride of its weight)
     int32_t chunk_off[NFL_MAX_CHUNKS + 1];   // byte offset of each chunk in the stream (+ end)
+    int32_t chunk_aux[NFL_MAX_CHUNKS + 1];   // dgrad: stash slot (k-step index inside a segment's activation record)
+                                             // whose 2 KiB is DMA'd beside the chunk as the relu mask; -1 = none
     NflRowTile rt[NFL_MAX_RT];
 };
+
+#if defined(__HIPCC__)
+#define NFL_HD __host__ __device__ inline
+#else
+#define NFL_HD inline
+#endif
+// ---- per-segment (32 samples) stash records, in k-steps of 1 KiB (64 lanes x 8 bf16) ----
+// forward activations (inputs of every layer), written by the training-mode forward:
+//   P | h1..h8 | feat | D (dir PE 2, appearance 3) | dirh | tau | g1..g4
+NFL_HD constexpr int nfl_act_h(int nkp, int l) { return nkp + 16 * (l - 1); }   // l = 1..8
+NFL_HD constexpr int nfl_act_feat(int nkp) { return nkp + 128; }
+NFL_HD constexpr int nfl_act_d(int nkp) { return nkp + 144; }
+NFL_HD constexpr int nfl_act_dirh(int nkp) { return nkp + 149; }
+NFL_HD constexpr int nfl_act_tau(int nkp) { return nkp + 157; }
+NFL_HD constexpr int nfl_act_g(int nkp, int m) { return nkp + 158 + 8 * (m - 1); }   // m = 1..4
+NFL_HD constexpr int nfl_act_slots(int nkp) { return nkp + 190; }
+// pre-activation gradients, written by the dgrad kernel:
+//   d1..d8 | dfeat | ddirh | dg1..dg4 | head grads as natural k-steps: dsigma, drgb, dsigma_t, drgb_t, dbeta
+#define NFL_GRD_D(l) (16 * ((l) - 1))
+#define NFL_GRD_FEAT 128
+#define NFL_GRD_DIRH 144
+#define NFL_GRD_G(m) (152 + 8 * ((m) - 1))
+#define NFL_GRD_HEADS 184
+#define NFL_GRD_SLOTS 189
 
 #ifdef __cplusplus
 extern "C" {
@@ -77,6 +110,7 @@ extern "C" {
 struct nfl_field_desc;
 // returns 0 or a negative NFL_E* code
 int nfl_plan_fill(const struct nfl_field_desc* desc, int prec, struct NflPlan* plan);
+int nfl_plan_fill_bwd(const struct nfl_field_desc* desc, struct NflPlan* plan);
 #ifdef __cplusplus
 }
 #endif

@@ -36,7 +36,13 @@
 #include "nfl_plan.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+template <class V8> struct nfl_elem;
+template <> struct nfl_elem<h8> { using type = _Float16; };
+template <> struct nfl_elem<b8> { using type = __bf16; };
+__device__ __forceinline__ f16v nfl_mfma(h8 a, h8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f16v nfl_mfma(b8 a, b8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 #define NFL_DEV __device__ __forceinline__
@@ -109,14 +115,23 @@ NFL_DEV float nfl_pe_feature(int f, const float (&raw)[3], const float (&th)[3],
     return nfl_sin_rev(r);
 }
 
-template <int NP>
-NFL_DEV void nfl_split8(const float (&v)[8], h8 (&dst)[NP]) {
+template <int NP, class V8>
+NFL_DEV void nfl_split8(const float (&v)[8], V8 (&dst)[NP]) {
+    using E = typename nfl_elem<V8>::type;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 hi = (_Float16)v[j];
+        const E hi = (E)v[j];
         dst[0][j] = hi;
-        if (NP == 2) dst[1][j] = (_Float16)(v[j] - (float)hi);
+        if (NP == 2) dst[1][j] = (E)(v[j] - (float)hi);
     }
+}
+
+// 8 values -> bf16 -> this lane's 16 B of a stash k-step (dst already includes lane*16)
+NFL_DEV void nfl_stash8(const float (&v)[8], char* dst) {
+    b8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (__bf16)v[j];
+    *reinterpret_cast<b8*>(dst) = t;
 }
 
 // natural-order B operand of one k-step of a positional encoding: lane half h holds
@@ -124,7 +139,7 @@ NFL_DEV void nfl_split8(const float (&v)[8], h8 (&dst)[NP]) {
 // instruction stream is uniform.
 template <int N, int NP>
 NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th)[3], const float (&tl)[3],
-                          h8 (&dst)[NP]) {
+                          h8 (&dst)[NP], char* stash = nullptr) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -146,6 +161,7 @@ NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th
         }
     }
     nfl_split8<NP>(v, dst);
+    if (stash) nfl_stash8(v, stash);
 }
 
 // ---------------------------------------------------------------------------------
@@ -215,29 +231,29 @@ NFL_DEV void nfl_bias_init(f16v (&acc)[NCB], const float* bias_rt, int h) {
 }
 
 // acc += W[frag0 .. frag0+NK) * in[ks0 .. ks0+NK)
-template <int NP, int NCB, int NK, int NIN>
-NFL_DEV void nfl_mma(f16v (&acc)[NCB], const h8 (&in)[NIN][NCB][NP], int ks0, const char* wl, int frag0) {
+template <int NP, int NCB, int NK, int NIN, class V8>
+NFL_DEV void nfl_mma(f16v (&acc)[NCB], const V8 (&in)[NIN][NCB][NP], int ks0, const char* wl, int frag0) {
     constexpr int KSB = 1024 * NP;
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
-        const h8 whi = *reinterpret_cast<const h8*>(wl + (frag0 + k) * KSB);
+        const V8 whi = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB);
         if (NP == 2) {
-            const h8 wlo = *reinterpret_cast<const h8*>(wl + (frag0 + k) * KSB + 1024);
+            const V8 wlo = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB + 1024);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, in[ks0 + k][cb][0], acc[cb], 0, 0, 0);
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, in[ks0 + k][cb][NP - 1], acc[cb], 0, 0, 0);
+                acc[cb] = nfl_mfma(wlo, in[ks0 + k][cb][0], acc[cb]);
+                acc[cb] = nfl_mfma(whi, in[ks0 + k][cb][NP - 1], acc[cb]);
             }
         }
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-            acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(whi, in[ks0 + k][cb][0], acc[cb], 0, 0, 0);
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = nfl_mfma(whi, in[ks0 + k][cb][0], acc[cb]);
     }
 }
 
 // accumulator tile -> the two k-steps (2*tile, 2*tile+1) of the next layer's B operand
 template <int NP, int NCB, bool RELU, int NOUT>
-NFL_DEV void nfl_store_act(const f16v (&acc)[NCB], h8 (&out)[NOUT][NCB][NP], int ks) {
+NFL_DEV void nfl_store_act(const f16v (&acc)[NCB], h8 (&out)[NOUT][NCB][NP], int ks,
+                           char* const (&stash)[NCB], int slot) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -249,6 +265,7 @@ NFL_DEV void nfl_store_act(const f16v (&acc)[NCB], h8 (&out)[NOUT][NCB][NP], int
                 v[j] = RELU ? fmaxf(x, 0.f) : x;
             }
             nfl_split8<NP>(v, out[ks + s][cb]);
+            if (stash[cb]) nfl_stash8(v, stash[cb] + (slot + s) * 1024);
         }
 }
 
@@ -258,7 +275,7 @@ template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, int NI
 NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
                        const h8 (&inA)[NINA][NCB][NP], int ksA0,
                        const h8 (&inB)[NINB][NCB][NP], int ksB0,
-                       h8 (&out)[NOUT][NCB][NP], int out_ks0) {
+                       h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&stash)[NCB], int slot0) {
     f16v acc[2][NCB];
     const char* wl = nullptr;
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
@@ -268,9 +285,9 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         nfl_mma<NP, NCB, NKA, NINA>(acc[i & 1], inA, ksA0, wl, frag0);
         if (NKB > 0) nfl_mma<NP, NCB, NKB, NINB>(acc[i & 1], inB, ksB0, wl, frag0 + NKA);
-        if (i > 0) nfl_store_act<NP, NCB, RELU, NOUT>(acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1));
+        if (i > 0) nfl_store_act<NP, NCB, RELU, NOUT>(acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1));
     });
-    nfl_store_act<NP, NCB, RELU, NOUT>(acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1));
+    nfl_store_act<NP, NCB, RELU, NOUT>(acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1));
     rt += NRT;
 }
 
@@ -384,6 +401,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         float s_z[NCB], s_dl[NCB];
         h8 P[NKP][NCB][NP];
         h8 X[16][NCB][NP], Y[16][NCB][NP];
+        char* st[NCB];        // this lane's slice of the segment's activation record (training forward) or null
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int g = tile * NSLOT + wave * NCB + cb;        // segment index inside this workgroup
@@ -399,6 +417,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             const float near = r1[2], far = r1[3];
             const float z = nfl_z_at(a, ray, near, far, ii);
             const float zn = ii + 1 < N ? nfl_z_at(a, ray, near, far, ii + 1) : z;
+            st[cb] = (a.d_act_stash && seg_ok)
+                         ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + lane * 16
+                         : nullptr;
             s_ray[cb] = ray;
             s_idx[cb] = ii;
             s_ok[cb] = ok;
@@ -413,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             for (int k = 0; k < 3; ++k) nfl_turns(raw[k], th[k], tl[k]);
 #pragma unroll
             for (int ks = 0; ks < NKP; ++ks) {
-                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, P[ks][cb]);
+                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, P[ks][cb], st[cb] ? st[cb] + ks * 1024 : nullptr);
                 __builtin_amdgcn_sched_barrier(0);      // bound the register pressure of the encoder
             }
         }
@@ -423,14 +444,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         // raw head outputs of sample c (lane half 0); extracted at once so the 16-register
         // accumulator tiles die immediately
         float o_sig[NCB], o_rgb[NCB][3], o_tr[NCB][5];
-        nfl_dense<NP, NCB, NKP, 0, true, 8, 2>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0);       // L1
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L2
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0);        // L3
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L4
-        nfl_dense<NP, NCB, NKP, 16, true, 8, 1>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0);      // L5 (skip)
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L6
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0);        // L7
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0);        // L8
+        nfl_dense<NP, NCB, NKP, 0, true, 8, 2>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1));       // L1
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2));        // L2
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3));        // L3
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4));        // L4
+        nfl_dense<NP, NCB, NKP, 16, true, 8, 1>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5));      // L5 (skip)
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6));        // L6
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7));        // L7
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8));        // L8
         {
             f16v hacc[NCB];
             nfl_head<NP, NCB, 16>(ring, bias_lds, rt, h, Y, 0, hacc);                          // sigma
@@ -438,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             for (int cb = 0; cb < NCB; ++cb) o_sig[cb] = hacc[cb][0];
         }
         if (!a.sigma_only) {
-            nfl_dense<NP, NCB, 16, 0, false, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0);   // final (linear)
+            nfl_dense<NP, NCB, 16, 0, false, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP));   // final (linear)
             {
                 h8 D[5][NCB][NP];
 #pragma unroll
@@ -451,9 +472,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         raw[k] = dp[k];
                         nfl_turns(raw[k], th[k], tl[k]);
                     }
-                    nfl_pe_kstep<4, NP>(0, h, raw, th, tl, D[0][cb]);
+                    char* sd = st[cb] ? st[cb] + nfl_act_d(NKP) * 1024 : nullptr;
+                    nfl_pe_kstep<4, NP>(0, h, raw, th, tl, D[0][cb], sd);
                     __builtin_amdgcn_sched_barrier(0);
-                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, D[1][cb]);
+                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, D[1][cb], sd ? sd + 1024 : nullptr);
                     __builtin_amdgcn_sched_barrier(0);
                     if (A.has_a) {
                         const float* ap = a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;
@@ -463,13 +485,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                             const f4v v1 = *reinterpret_cast<const f4v*>(ap + 16 * ks + 4);
                             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                             nfl_split8<NP>(v, D[2 + ks][cb]);
+                            if (sd) nfl_stash8(v, sd + (2 + ks) * 1024);
                         }
                     }
                 }
                 if (A.has_a)
-                    nfl_dense<NP, NCB, 16, 5, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0);
+                    nfl_dense<NP, NCB, 16, 5, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
                 else
-                    nfl_dense<NP, NCB, 16, 2, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0);
+                    nfl_dense<NP, NCB, 16, 2, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
             }
             {
                 f16v hacc[NCB];
@@ -490,11 +513,12 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     const f4v v1 = *reinterpret_cast<const f4v*>(tp + 4);
                     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     nfl_split8<NP>(v, T[0][cb]);
+                    if (st[cb]) nfl_stash8(v, st[cb] + nfl_act_tau(NKP) * 1024);
                 }
-                nfl_dense<NP, NCB, 16, 1, true, 4, 1>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0);
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8);
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0);
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8);
+                nfl_dense<NP, NCB, 16, 1, true, 4, 1>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0, st, nfl_act_g(NKP, 1));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 2));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0, st, nfl_act_g(NKP, 3));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 4));
                 f16v hacc[NCB];
                 nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 8, hacc);
 #pragma unroll

@@ -1,0 +1,343 @@
+// nfl_wgrad.hip -- weight / bias gradients of the field MLP as streaming bf16 GEMMs.
+//
+//   dW_l[out, in] = sum over samples  delta_l[sample, out] * h_{l-1}[sample, in]
+//   db_l[out]     = sum over samples  delta_l[sample, out]
+// (what autograd's Linear backward does per point chunk in the reference, models/nerf.py
+// 153-212).  Both operands come from the stashes the forward / dgrad kernels wrote: per
+// 32-sample segment, per layer, MFMA-fragment-ordered bf16 with the SAMPLE on the lane.
+// The contraction index here is the sample, so both operands have to be presented with
+// the FEATURE on the lane and 8 consecutive samples in registers: the 1 KiB k-step images
+// are DMA'd verbatim into LDS and read back with ds_read_b64_tr_b16 (hardware 4x16
+// transpose), two reads per MFMA operand, no extra pass over the data.
+//
+// Roofline: HBM.  A 256x256 layer reads 32 KiB per segment for 2 x 64 MFMAs, 128 FLOP/B,
+// far under the MFMA ridge, so the kernel is a stream: 3-slot LDS ring fed by
+// global_load_lds, one barrier per segment, fp32 accumulators for the whole (<=256 x <=352)
+// tile of dW in registers, one fp32 atomic flush per workgroup at the end.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "../../include/nerf_fl_amd.h"
+#include "nfl_plan.h"
+
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+#define WG_MAX_OT 8      // out tiles (32 features) per job
+#define WG_MAX_IT 11     // in tiles per job
+#define WG_NOT 2         // out tiles per wave
+#define WG_MAXPW 10      // 1 KiB DMA pieces per wave per segment
+#define WG_SLOT (2048 * (WG_MAX_OT + WG_MAX_IT))
+
+struct WgTile {
+    int16_t slot;        // first k-step of the tile inside the segment record
+    int16_t kind;        // NFL_SEG_ACT / NFL_SEG_NAT
+    int16_t idx0;        // row0 / col0 of feature 0 of this tile in the weight
+    int16_t nvalid;      // features of this tile that exist (<= 32)
+};
+struct WgJob {
+    int32_t layer;       // NFL_P_* of the weight this job accumulates into
+    int32_t ld;          // row stride of that weight
+    int32_t n_ot, n_it;
+    int32_t n_wo, n_wi;  // waves across out tiles / in tiles (n_wo * n_wi == 4)
+    int32_t do_bias;
+    int32_t bias_layer_of_ot[WG_MAX_OT];   // heads: each out tile may belong to another layer (-1: use `layer`)
+    WgTile ot[WG_MAX_OT];
+    WgTile it[WG_MAX_IT];
+};
+struct WgArgs {
+    const char* act;     // activation stash
+    const char* grd;     // gradient stash
+    int act_slots, grd_slots;
+    int n_seg, seg_per_wg;
+    nfl_field_grads g;
+    int n_jobs;
+    WgJob job[10];
+};
+
+__device__ __forceinline__ int wg_orig(int kind, int i) {
+    return kind == NFL_SEG_ACT ? 16 * (i >> 4) + 8 * ((i & 7) >> 2) + 4 * ((i >> 3) & 1) + (i & 3) : i;
+}
+
+// feature-on-lane MFMA operand of MFMA k-step m (samples 16m..16m+15) from a 2 KiB tile image
+__device__ __forceinline__ b8 wg_operand(const char* tile, int lane, int m) {
+    const int g = lane >> 4, ip = lane & 15, q = ip >> 2, p = ip & 3;
+    const int c = 16 * m + 8 * (g >> 1) + q;
+    const char* ad = tile + (g & 1) * 1024 + (((p >> 1) * 32 + c) * 8 + 4 * (p & 1)) * 2;
+    const b4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad));
+    const b4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad + 4 * 8 * 2));
+    b8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+template <int I0, int I1, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        wg_static_for<I0 + 1, I1>(f);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WgJob& J = A.job[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave % J.n_wo, wi = wave / J.n_wo;
+    int seg0 = blockIdx.x * A.seg_per_wg, seg1 = seg0 + A.seg_per_wg;
+    if (seg1 > A.n_seg) seg1 = A.n_seg;
+    if (seg0 >= seg1) return;
+    const int n_pieces = 2 * (J.n_ot + J.n_it);
+
+    // this wave's DMA pieces: source base (+ lane*16), per-segment stride, LDS offset
+    const char* psrc[WG_MAXPW];
+    size_t pstride[WG_MAXPW];
+    int pdst[WG_MAXPW];
+#pragma unroll
+    for (int pp = 0; pp < WG_MAXPW; ++pp) {
+        int p = wave + 4 * pp;
+        p = p < n_pieces ? p : n_pieces - 1;
+        const int t = p >> 1;
+        const bool is_out = t < J.n_ot;
+        const int slot = (is_out ? J.ot[t].slot : J.it[t - J.n_ot].slot) + (p & 1);
+        psrc[pp] = (is_out ? A.grd : A.act) + (size_t)slot * 1024 + lane * 16;
+        pstride[pp] = (size_t)(is_out ? A.grd_slots : A.act_slots) * 1024;
+        pdst[pp] = p * 1024;
+    }
+    auto issue = [&](int seg, int s) __attribute__((always_inline)) {
+        const int sg = seg < seg1 ? seg : seg1 - 1;          // surplus issues re-read the last segment
+#pragma unroll
+        for (int pp = 0; pp < WG_MAXPW; ++pp)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(psrc[pp] + (size_t)sg * pstride[pp]),
+                (__attribute__((address_space(3))) void*)(smem + s * WG_SLOT + pdst[pp]), 16, 0, 0);
+    };
+
+    f16v acc[WG_NOT][WG_MAX_IT];
+#pragma unroll
+    for (int a = 0; a < WG_NOT; ++a)
+#pragma unroll
+        for (int b = 0; b < WG_MAX_IT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[WG_NOT] = {0.f, 0.f};
+    // in tiles of this wave: wi, wi + n_wi, ...
+    const int n_my_it = (J.n_it - wi + J.n_wi - 1) / J.n_wi;
+
+    issue(seg0, 0);
+    issue(seg0 + 1, 1);
+    int s_read = 0, s_issue = 2;
+    for (int seg = seg0; seg < seg1; ++seg) {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WG_MAXPW) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(seg + 2, s_issue);
+        s_issue = s_issue == 2 ? 0 : s_issue + 1;
+        const char* base = smem + s_read * WG_SLOT;
+        s_read = s_read == 2 ? 0 : s_read + 1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            b8 av[WG_NOT];
+#pragma unroll
+            for (int a = 0; a < WG_NOT; ++a) {
+                const int ot = wo * WG_NOT + a;
+                if (ot < J.n_ot) {
+                    av[a] = wg_operand(base + ot * 2048, lane, m);
+                    if (J.do_bias && wi == 0) {
+                        float s = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s += (float)av[a][j];
+                        bsum[a] += s;
+                    }
+                }
+            }
+            wg_static_for<0, WG_MAX_IT>([&](auto B) __attribute__((always_inline)) {
+                constexpr int b = decltype(B)::value;
+                if (b < n_my_it) {
+                    const int it = wi + b * J.n_wi;
+                    const b8 bv = wg_operand(base + (J.n_ot + it) * 2048, lane, m);
+#pragma unroll
+                    for (int a = 0; a < WG_NOT; ++a)
+                        if (wo * WG_NOT + a < J.n_ot)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv, acc[a][b], 0, 0, 0);
+                }
+            });
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // flush: fp32 atomics into the nn.Linear-layout gradient tensors
+    const int n = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < WG_NOT; ++a) {
+        const int ot = wo * WG_NOT + a;
+        if (ot >= J.n_ot) continue;
+        const WgTile TO = J.ot[ot];
+        const int layer = J.bias_layer_of_ot[ot] >= 0 ? J.bias_layer_of_ot[ot] : J.layer;
+        float* W = A.g.weight[layer];
+        wg_static_for<0, WG_MAX_IT>([&](auto B) __attribute__((always_inline)) {
+            constexpr int b = decltype(B)::value;
+            if (b < n_my_it && W != nullptr) {
+                const WgTile TI = J.it[wi + b * J.n_wi];
+                const int on = wg_orig(TI.kind, n);
+                if (on < TI.nvalid) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int oi = wg_orig(TO.kind, (r & 3) + 8 * (r >> 2) + 4 * hh);
+                        if (oi < TO.nvalid) atomicAdd(W + (size_t)(TO.idx0 + oi) * J.ld + TI.idx0 + on, acc[a][b][r]);
+                    }
+                }
+            }
+        });
+        if (J.do_bias && wi == 0 && A.g.bias[layer] != nullptr) {
+            const float tot = bsum[a] + __shfl_xor(bsum[a], 32);
+            const int oi = wg_orig(TO.kind, n);
+            if (hh == 0 && oi < TO.nvalid) atomicAdd(A.g.bias[layer] + TO.idx0 + oi, tot);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+static void add_tiles(WgTile* dst, int& n, int slot0, int kind, int idx0, int count) {
+    for (int t = 0; 32 * t < count; ++t) {
+        WgTile w;
+        w.slot = (int16_t)(slot0 + 2 * t);
+        w.kind = (int16_t)kind;
+        w.idx0 = (int16_t)(idx0 + 32 * t);
+        w.nvalid = (int16_t)(count - 32 * t < 32 ? count - 32 * t : 32);
+        dst[n++] = w;
+    }
+}
+static WgJob make_job(int layer, int ld, bool bias) {
+    WgJob j;
+    memset(&j, 0, sizeof(j));
+    j.layer = layer;
+    j.ld = ld;
+    j.do_bias = bias ? 1 : 0;
+    for (int i = 0; i < WG_MAX_OT; ++i) j.bias_layer_of_ot[i] = -1;
+    return j;
+}
+static void finish_job(WgJob& j) {
+    if (j.n_ot > 4) { j.n_wo = 4; j.n_wi = 1; }          // 2 out tiles per wave, all in tiles
+    else if (j.n_ot > 2) { j.n_wo = 2; j.n_wi = 2; }
+    else { j.n_wo = 1; j.n_wi = 4; }                     // heads: split the in tiles
+}
+
+extern "C" int nfl_mlp_wgrad(const nfl_field_desc* d, const char* d_act_stash, const char* d_grad_stash,
+                             int32_t n_rays, int32_t n_samples, int32_t use_transient,
+                             const nfl_field_grads* grads, void* stream) {
+    NflPlan p;
+    if (!d || !d_act_stash || !d_grad_stash || !grads) return NFL_EINVAL;
+    if (nfl_plan_fill(d, NFL_PREC_F16X3, &p) != NFL_OK) return NFL_EINVAL;
+    if (n_rays < 0 || n_samples < 1) return NFL_EINVAL;
+    if (n_rays == 0) return NFL_OK;
+    const int nkp = p.nkp, cx = 6 * d->n_emb_xyz + 3, W = NFL_W, H = NFL_W / 2;
+    const bool ut = p.has_t && use_transient;
+    WgArgs A;             // kernel argument block, built on the host each call
+    memset(&A, 0, sizeof(A));
+    WgJob jobs[24];
+    A.act = d_act_stash;
+    A.grd = d_grad_stash;
+    A.act_slots = nfl_act_slots(nkp);
+    A.grd_slots = NFL_GRD_SLOTS;
+    A.n_seg = n_rays * ((n_samples + 31) / 32);
+    A.g = *grads;
+    int nj = 0;
+    auto push = [&](WgJob j) { finish_job(j); jobs[nj++] = j; };
+    for (int l = 1; l <= 8; ++l) {
+        WgJob j = make_job(NFL_P_XYZ1 + l - 1, p.ld[NFL_P_XYZ1 + l - 1], true);
+        add_tiles(j.ot, j.n_ot, NFL_GRD_D(l), NFL_SEG_ACT, 0, W);
+        if (l == 1 || l == 5) {
+            add_tiles(j.it, j.n_it, 0, NFL_SEG_NAT, 0, cx);
+            if (l == 5) {
+                push(j);
+                j = make_job(NFL_P_XYZ1 + 4, p.ld[NFL_P_XYZ1 + 4], false);
+                add_tiles(j.ot, j.n_ot, NFL_GRD_D(5), NFL_SEG_ACT, 0, W);
+                add_tiles(j.it, j.n_it, nfl_act_h(nkp, 4), NFL_SEG_ACT, cx, W);
+            }
+        } else {
+            add_tiles(j.it, j.n_it, nfl_act_h(nkp, l - 1), NFL_SEG_ACT, 0, W);
+        }
+        push(j);
+    }
+    {   // sigma head
+        WgJob j = make_job(NFL_P_SIGMA, W, true);
+        add_tiles(j.ot, j.n_ot, NFL_GRD_HEADS + 0, NFL_SEG_NAT, 0, 1);
+        add_tiles(j.it, j.n_it, nfl_act_h(nkp, 8), NFL_SEG_ACT, 0, W);
+        push(j);
+    }
+    {   // xyz_encoding_final
+        WgJob j = make_job(NFL_P_FINAL, W, true);
+        add_tiles(j.ot, j.n_ot, NFL_GRD_FEAT, NFL_SEG_ACT, 0, W);
+        add_tiles(j.it, j.n_it, nfl_act_h(nkp, 8), NFL_SEG_ACT, 0, W);
+        push(j);
+    }
+    {   // dir_encoding: inputs [feat | dir PE | appearance]
+        WgJob j = make_job(NFL_P_DIR, p.ld[NFL_P_DIR], true);
+        add_tiles(j.ot, j.n_ot, NFL_GRD_DIRH, NFL_SEG_ACT, 0, H);
+        add_tiles(j.it, j.n_it, nfl_act_feat(nkp), NFL_SEG_ACT, 0, W);
+        add_tiles(j.it, j.n_it, nfl_act_d(nkp), NFL_SEG_NAT, W, 27);
+        if (p.has_a) add_tiles(j.it, j.n_it, nfl_act_d(nkp) + 2, NFL_SEG_NAT, W + 27, p.n_a);
+        push(j);
+    }
+    {   // rgb head
+        WgJob j = make_job(NFL_P_RGB, H, true);
+        add_tiles(j.ot, j.n_ot, NFL_GRD_HEADS + 1, NFL_SEG_NAT, 0, 3);
+        add_tiles(j.it, j.n_it, nfl_act_dirh(nkp), NFL_SEG_ACT, 0, H);
+        push(j);
+    }
+    if (ut) {
+        {
+            WgJob j = make_job(NFL_P_T0, p.ld[NFL_P_T0], true);
+            add_tiles(j.ot, j.n_ot, NFL_GRD_G(1), NFL_SEG_ACT, 0, H);
+            add_tiles(j.it, j.n_it, nfl_act_feat(nkp), NFL_SEG_ACT, 0, W);
+            add_tiles(j.it, j.n_it, nfl_act_tau(nkp), NFL_SEG_NAT, W, d->n_tau);
+            push(j);
+        }
+        for (int m = 2; m <= 4; ++m) {
+            WgJob j = make_job(NFL_P_T0 + m - 1, H, true);
+            add_tiles(j.ot, j.n_ot, NFL_GRD_G(m), NFL_SEG_ACT, 0, H);
+            add_tiles(j.it, j.n_it, nfl_act_g(nkp, m - 1), NFL_SEG_ACT, 0, H);
+            push(j);
+        }
+        {   // the three transient heads share the g4 stream: one out "tile" each
+            WgJob j = make_job(NFL_P_TSIGMA, H, true);
+            add_tiles(j.ot, j.n_ot, NFL_GRD_HEADS + 2, NFL_SEG_NAT, 0, 1);
+            add_tiles(j.ot, j.n_ot, NFL_GRD_HEADS + 3, NFL_SEG_NAT, 0, 3);
+            add_tiles(j.ot, j.n_ot, NFL_GRD_HEADS + 4, NFL_SEG_NAT, 0, 1);
+            j.bias_layer_of_ot[0] = NFL_P_TSIGMA;
+            j.bias_layer_of_ot[1] = NFL_P_TRGB;
+            j.bias_layer_of_ot[2] = NFL_P_TBETA;
+            add_tiles(j.it, j.n_it, nfl_act_g(nkp, 4), NFL_SEG_ACT, 0, H);
+            push(j);
+        }
+    }
+    A.n_jobs = nj;
+    // K split: enough workgroups to fill the chip about twice
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    int nsplit = (2 * ncu + nj - 1) / nj;
+    if (nsplit > A.n_seg) nsplit = A.n_seg;
+    if (nsplit < 1) nsplit = 1;
+    A.seg_per_wg = (A.n_seg + nsplit - 1) / nsplit;
+    nsplit = (A.n_seg + A.seg_per_wg - 1) / A.seg_per_wg;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WG_SLOT) != hipSuccess)
+            return NFL_ENODEV;
+        attr_set = true;
+    }
+    for (int j0 = 0; j0 < nj; j0 += 10) {       // the argument block holds 10 jobs (< 4 KiB of kernel arguments)
+        const int n = nj - j0 < 10 ? nj - j0 : 10;
+        memcpy(A.job, jobs + j0, n * sizeof(WgJob));
+        A.n_jobs = n;
+        hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(nsplit, n), dim3(256), 3 * WG_SLOT, static_cast<hipStream_t>(stream), A);
+    }
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}

@@ -89,13 +89,37 @@ class _PackedField:
         self.packed_bytes = L.nfl_packed_bytes(C.byref(self.desc), prec)
         self.packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=device)
         self.key = None
+        # dgrad stream (transposed weights, bf16 hi+lo); built lazily on the first training forward
+        self.h_bplan = self.d_bplan = self.bpacked = None
+        self.bkey = None
 
-    def ensure_packed(self):
-        model = self.model_ref()
-        params = dict(model.named_parameters())
-        key = tuple((n, p.data_ptr(), p._version) for n, p in params.items())
-        if key == self.key:
+    def param_list(self):
+        """(layer index, weight, bias) for every layer this field has, in NFL_P_* order."""
+        params = dict(self.model_ref().named_parameters())
+        out = []
+        for i, name in enumerate(_lib.LAYER_NAMES):
+            if name + ".weight" in params:
+                out.append((i, params[name + ".weight"], params[name + ".bias"]))
+        return out
+
+    def ensure_bwd_packed(self):
+        L = _lib.lib()
+        if self.h_bplan is None:
+            nbytes = L.nfl_plan_bytes(C.byref(self.desc))
+            self.h_bplan = C.create_string_buffer(nbytes)
+            _lib.check(L.nfl_bwd_plan_build(C.byref(self.desc), self.h_bplan, nbytes), "nfl_bwd_plan_build")
+            self.d_bplan = torch.frombuffer(bytearray(self.h_bplan.raw), dtype=torch.uint8).to(self.device)
+            self.bpacked_bytes = L.nfl_bwd_packed_bytes(C.byref(self.desc))
+            self.bpacked = torch.empty(self.bpacked_bytes, dtype=torch.uint8, device=self.device)
+        if self.bkey == self.key:
             return
+        fp, _keep = self._field_params()
+        _lib.check(L.nfl_pack_field(self.h_bplan, _ptr(self.d_bplan), C.byref(fp), _ptr(self.bpacked),
+                                    self.bpacked_bytes, _stream()), "nfl_pack_field(bwd)")
+        self.bkey = self.key
+
+    def _field_params(self):
+        params = dict(self.model_ref().named_parameters())
         fp = _lib.FieldParams()
         keep = []
         for i, name in enumerate(_lib.LAYER_NAMES):
@@ -108,6 +132,15 @@ class _PackedField:
             keep += [w, b]
             fp.weight[i] = w.data_ptr()
             fp.bias[i] = b.data_ptr()
+        return fp, keep
+
+    def ensure_packed(self):
+        model = self.model_ref()
+        params = dict(model.named_parameters())
+        key = tuple((n, p.data_ptr(), p._version) for n, p in params.items())
+        if key == self.key:
+            return
+        fp, _keep = self._field_params()
         _lib.check(_lib.lib().nfl_pack_field(self.h_plan, _ptr(self.d_plan), C.byref(fp), _ptr(self.packed),
                                              self.packed_bytes, _stream()), "nfl_pack_field")
         self.key = key
@@ -142,7 +175,7 @@ def _n_freqs(emb):
 
 def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, perturb=0.0, use_disp=False,
               noise=None, noise_std=0.0, a_emb=None, t_emb=None, view_dir=None, sigma_only=False,
-              white_back=False, test_extras=False, want_rgb=True, want_z=False, field_raw=False):
+              white_back=False, test_extras=False, want_rgb=True, want_z=False, field_raw=False, stash=False):
     R = rays.shape[0]
     dev = rays.device
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -158,8 +191,11 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
                        rgb_transient_only=new(R, 3), depth_transient_only=new(R))
     if want_z:
         out["z"] = new(R, n_samples)
-    if field_raw:
+    if field_raw or stash:
         out["field_raw"] = torch.zeros(R * n_samples, 9, dtype=torch.float32, device=dev)
+    if stash:
+        nb = _lib.lib().nfl_act_stash_bytes(C.byref(field.desc), R, n_samples)
+        out["act_stash"] = torch.empty(nb, dtype=torch.uint8, device=dev)
     a = _lib.PassArgs()
     a.d_rays, a.d_view_dir = _ptr(rays), _ptr(view_dir)
     a.n_rays, a.n_samples = R, n_samples
@@ -177,9 +213,159 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     a.d_rgb_transient_only = _ptr(out.get("rgb_transient_only"))
     a.d_depth_transient_only = _ptr(out.get("depth_transient_only"))
     a.d_field_raw = _ptr(out.get("field_raw"))
+    a.d_act_stash = _ptr(out.get("act_stash"))
     _lib.check(_lib.lib().nfl_render_pass(field.h_plan, _ptr(field.d_plan), _ptr(field.packed), C.byref(a), _stream()),
                "nfl_render_pass")
     return out
+
+
+def _forward(cfg, rays, a_emb, t_emb, train):
+    """Both passes + hierarchical sampling.  Returns (result dict in the reference's key
+    order, state saved for the backward or None)."""
+    f_c, f_f = cfg["f_c"], cfg["f_f"]
+    R, dev, S, I = rays.shape[0], rays.device, cfg["S"], cfg["I"]
+    test_time, raw = cfg["test_time"], cfg["raw"]
+    result, saved = {}, {}
+    oc = _run_pass(f_c, rays, S, lin=_linspace(S, dev), perturb_rand=cfg["perturb_rand"], perturb=cfg["perturb"],
+                   use_disp=cfg["use_disp"], noise=cfg["noise_c"], noise_std=cfg["noise_std"],
+                   view_dir=cfg["view_dir"], sigma_only=test_time, white_back=cfg["white_back"],
+                   want_z=I > 0 or train, field_raw=raw, stash=train)
+    result["weights_coarse"] = oc["weights"]
+    result["opacity_coarse"] = oc["opacity"]
+    if not test_time:
+        result["rgb_coarse"] = oc["rgb"]
+        result["depth_coarse"] = oc["depth"]
+    if raw:
+        result["_field_raw_coarse"] = oc["field_raw"]
+    if train:
+        saved["coarse"] = dict(z=oc["z"], field_raw=oc["field_raw"], act=oc["act_stash"], noise=cfg["noise_c"],
+                               use_t=False, n=S)
+    if I > 0:
+        F = S + I
+        z_fine = torch.empty(R, F, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().nfl_sample_pdf(_ptr(oc["z"]), _ptr(oc["weights"]), _ptr(cfg["u"]), _ptr(cfg["u_row"]),
+                                             R, S, I, _ptr(z_fine), C.c_void_p(0), _stream()), "nfl_sample_pdf")
+        use_t = cfg["use_t"]
+        of = _run_pass(f_f, rays, F, z=z_fine, noise=cfg["noise_f"], noise_std=cfg["noise_std"], a_emb=a_emb,
+                       t_emb=t_emb if use_t else None, view_dir=cfg["view_dir"], white_back=cfg["white_back"],
+                       test_extras=test_time, field_raw=raw, stash=train)
+        result["weights_fine"] = of["weights"]
+        result["opacity_fine"] = of["opacity"]
+        if use_t:
+            result["transient_sigmas"] = of["transient_sigmas"]
+            result["beta"] = of["beta"]
+            result["_rgb_fine_static"] = of["rgb_static"]
+            result["_rgb_fine_transient"] = of["rgb_transient"]
+            result["rgb_fine"] = of["rgb"]
+            if test_time:
+                result["rgb_fine_static"] = of["rgb_static_only"]
+                result["depth_fine_static"] = of["depth_static_only"]
+                result["rgb_fine_transient"] = of["rgb_transient_only"]
+                result["depth_fine_transient"] = of["depth_transient_only"]
+        else:
+            result["rgb_fine"] = of["rgb"]
+        result["depth_fine"] = of["depth"]
+        if raw:
+            result["_field_raw_fine"] = of["field_raw"]
+            result["_z_fine"] = z_fine
+        if train:
+            saved["fine"] = dict(z=z_fine, field_raw=of["field_raw"], act=of["act_stash"], noise=cfg["noise_f"],
+                                 use_t=use_t, n=F)
+    return result, (saved if train else None)
+
+
+def _g(grads, keys, name):
+    """Contiguous fp32 gradient of output `name`, or None."""
+    if name not in keys:
+        return None
+    g = grads[keys.index(name)]
+    return None if g is None else g.contiguous()
+
+
+def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents):
+    """One pass (coarse or fine) of the hand-written backward.  Returns (flat fp32 parameter
+    gradient arena views per parameter, g_a_emb, g_t_emb)."""
+    L = _lib.lib()
+    R, N, dev = rays.shape[0], st["n"], rays.device
+    use_t = bool(st["use_t"])
+    head = torch.empty(R * N, 9, dtype=torch.float32, device=dev)
+    ca = _lib.CompBwdArgs()
+    ca.d_field_raw, ca.d_z, ca.d_noise = _ptr(st["field_raw"]), _ptr(st["z"]), _ptr(st["noise"])
+    ca.noise_std, ca.n_rays, ca.n_samples = float(cfg["noise_std"]), R, N
+    ca.use_transient, ca.white_back = int(use_t), int(bool(cfg["white_back"]))
+    keep = [_g(grads, keys, f"weights_{typ}"), _g(grads, keys, f"opacity_{typ}"), _g(grads, keys, f"rgb_{typ}"),
+            _g(grads, keys, f"depth_{typ}")]
+    if use_t:
+        keep += [_g(grads, keys, "transient_sigmas"), _g(grads, keys, "beta"), _g(grads, keys, "_rgb_fine_static"),
+                 _g(grads, keys, "_rgb_fine_transient")]
+    else:
+        keep += [None, None, None, None]
+    (ca.g_weights, ca.g_opacity, ca.g_rgb, ca.g_depth, ca.g_transient_sigmas, ca.g_beta, ca.g_rgb_static,
+     ca.g_rgb_transient) = [_ptr(k) for k in keep]
+    ca.d_head_grads = _ptr(head)
+    _lib.check(L.nfl_composite_backward(C.byref(ca), _stream()), "nfl_composite_backward")
+
+    grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(field.desc), R, N), dtype=torch.uint8, device=dev)
+    g_a = g_t = None
+    if want_latents and field.desc.encode_appearance:
+        g_a = torch.zeros(R, field.desc.n_a, dtype=torch.float32, device=dev)
+    if want_latents and use_t:
+        g_t = torch.zeros(R, field.desc.n_tau, dtype=torch.float32, device=dev)
+    da = _lib.DgradArgs()
+    da.d_head_grads, da.d_act_stash, da.d_grad_stash = _ptr(head), _ptr(st["act"]), _ptr(grad_stash)
+    da.n_rays, da.n_samples, da.use_transient = R, N, int(use_t)
+    da.d_g_a_emb, da.d_g_t_emb = _ptr(g_a), _ptr(g_t)
+    _lib.check(L.nfl_mlp_dgrad(field.h_bplan, _ptr(field.d_bplan), _ptr(field.bpacked), C.byref(da), _stream()),
+               "nfl_mlp_dgrad")
+
+    plist = field.param_list()
+    arena = torch.zeros(sum(w.numel() + b.numel() for _, w, b in plist), dtype=torch.float32, device=dev)
+    fg = _lib.FieldGrads()
+    views, off = [], 0
+    for i, w, b in plist:
+        gw = arena[off:off + w.numel()].view_as(w)
+        off += w.numel()
+        gb = arena[off:off + b.numel()].view_as(b)
+        off += b.numel()
+        fg.weight[i], fg.bias[i] = gw.data_ptr(), gb.data_ptr()
+        views += [gw, gb]
+    _lib.check(L.nfl_mlp_wgrad(C.byref(field.desc), _ptr(st["act"]), _ptr(grad_stash), R, N, int(use_t),
+                               C.byref(fg), _stream()), "nfl_mlp_wgrad")
+    return views, g_a, g_t
+
+
+class _RenderRaysFn(torch.autograd.Function):
+    """autograd boundary: inputs are (cfg, rays, a_emb, t_emb, *parameters of coarse then fine);
+    gradients are produced by the HIP backward (composite -> dgrad -> wgrad) and handed to the
+    very nn.Parameter objects the optimizer / DDP hold."""
+
+    @staticmethod
+    def forward(ctx, cfg, rays, a_emb, t_emb, *params):
+        result, saved = _forward(cfg, rays, None if a_emb is None else _f32c(a_emb, "a_embedded"),
+                                 None if t_emb is None else _f32c(t_emb, "t_embedded"), train=True)
+        cfg["f_c"].ensure_bwd_packed()
+        if cfg["f_f"] is not None:
+            cfg["f_f"].ensure_bwd_packed()
+        keys = [k for k in result if not k.startswith("_field_raw") and k != "_z_fine"]
+        ctx.cfg, ctx.keys, ctx.saved, ctx.rays = cfg, keys, saved, rays
+        ctx.a_emb, ctx.t_emb = a_emb, t_emb
+        ctx.extra = {k: v for k, v in result.items() if k not in keys}
+        return tuple(result[k] for k in keys)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cfg, keys, saved, rays = ctx.cfg, ctx.keys, ctx.saved, ctx.rays
+        with torch.cuda.device(rays.device):
+            out = []
+            g_a = g_t = None
+            vc, _, _ = _backward_pass(cfg["f_c"], rays, saved["coarse"], "coarse", keys, grads, cfg, False)
+            out += vc
+            if cfg["f_f"] is not None:
+                vf, g_a, g_t = _backward_pass(cfg["f_f"], rays, saved["fine"], "fine", keys, grads, cfg, True)
+                out += vf
+        ga = g_a if (ctx.a_emb is not None and ctx.needs_input_grad[2]) else None
+        gt = g_t if (ctx.t_emb is not None and ctx.needs_input_grad[3]) else None
+        return (None, None, ga, gt, *out)
 
 
 def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, perturb=0, noise_std=1,
@@ -187,93 +373,84 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
     """See the reference docstring (models/rendering.py:63-81); `chunk` is accepted and
     ignored -- the fused kernel never materialises per-sample tensors, so there is
     nothing to chunk."""
-    if torch.is_grad_enabled() and any(p.requires_grad for m in models.values() for p in m.parameters()):
-        raise NotImplementedError(
-            "nerf_fl_amd.render_rays: the hand-written backward is not built yet; call under torch.no_grad()")
+    if isinstance(rays, torch.Tensor) and rays.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("gradients w.r.t. rays (--refine_pose) are not built yet")
     rays = _f32c(rays[:, :8] if rays.shape[1] > 8 else rays, "rays")
     if rays.dim() != 2 or rays.shape[1] != 8:
         raise ValueError("rays must be (N_rays, 8): origin, direction, near, far")
     R, dev = rays.shape[0], rays.device
     with torch.cuda.device(dev):
         n_xyz, n_dir = _n_freqs(embeddings["xyz"]), _n_freqs(embeddings["dir"])
-        coarse = models["coarse"]
-        view_dir = kwargs.get("view_dir")
-        if view_dir is not None:
-            view_dir = _f32c(view_dir, "view_dir", (R, 3))
-        S = int(N_samples)
-        raw = bool(kwargs.get("_field_raw", False))
-        result = {}
-
-        # ---- coarse pass (reference rendering.py:243-265)
-        f_c = _field(coarse, n_xyz, n_dir, dev)
-        perturb_rand = None
+        S, I = int(N_samples), int(N_importance)
+        F = S + I
+        test_time = bool(test_time)
+        cfg = dict(S=S, I=I, use_disp=bool(use_disp), perturb=float(perturb), noise_std=float(noise_std),
+                   white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
+                   view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
+                   use_t=False, f_f=None)
+        if kwargs.get("view_dir") is not None:
+            cfg["view_dir"] = _f32c(kwargs["view_dir"], "view_dir", (R, 3))
+        cfg["f_c"] = _field(models["coarse"], n_xyz, n_dir, dev)
+        # random draws, in the reference's order (rendering.py:258, 151, 30, 151)
         if perturb > 0:
-            perturb_rand = kwargs.get("perturb_rand")
-            perturb_rand = torch.rand(R, S, device=dev) if perturb_rand is None else _f32c(perturb_rand, "perturb_rand", (R, S))
-        noise_c = kwargs.get("noise_coarse")
-        noise_c = torch.randn(R, S, device=dev) if noise_c is None else _f32c(noise_c, "noise_coarse", (R, S))
-        oc = _run_pass(f_c, rays, S, lin=_linspace(S, dev), perturb_rand=perturb_rand, perturb=perturb,
-                       use_disp=use_disp, noise=noise_c if noise_std != 0 else None, noise_std=noise_std,
-                       view_dir=view_dir, sigma_only=bool(test_time), white_back=white_back,
-                       want_z=N_importance > 0, field_raw=raw)
-        result["weights_coarse"] = oc["weights"]
-        result["opacity_coarse"] = oc["opacity"]
-        if not test_time:
-            result["rgb_coarse"] = oc["rgb"]
-            result["depth_coarse"] = oc["depth"]
-        if raw:
-            result["_field_raw_coarse"] = oc["field_raw"]
-
-        if N_importance > 0:
-            # ---- hierarchical sampling (reference rendering.py:267-273, 7-46)
-            I = int(N_importance)
-            F = S + I
+            pr = kwargs.get("perturb_rand")
+            cfg["perturb_rand"] = torch.rand(R, S, device=dev) if pr is None else _f32c(pr, "perturb_rand", (R, S))
+        nc = kwargs.get("noise_coarse")
+        nc = torch.randn(R, S, device=dev) if nc is None else _f32c(nc, "noise_coarse", (R, S))
+        cfg["noise_c"] = nc if noise_std != 0 else None
+        a_emb = t_emb = None
+        params = [p for _, w, b in cfg["f_c"].param_list() for p in (w, b)]
+        if I > 0:
             if S < 3:
                 raise ValueError("N_samples must be >= 3 when N_importance > 0")
-            u = u_row = None
             if perturb == 0:
-                u_row = _linspace(I, dev)
+                cfg["u_row"] = _linspace(I, dev)
             else:
                 u = kwargs.get("u")
-                u = torch.rand(R, I, device=dev) if u is None else _f32c(u, "u", (R, I))
-            z_fine = torch.empty(R, F, dtype=torch.float32, device=dev)
-            _lib.check(_lib.lib().nfl_sample_pdf(_ptr(oc["z"]), _ptr(oc["weights"]), _ptr(u), _ptr(u_row), R, S, I,
-                                                 _ptr(z_fine), C.c_void_p(0), _stream()), "nfl_sample_pdf")
-            # ---- fine pass (reference rendering.py:275-287)
+                cfg["u"] = torch.rand(R, I, device=dev) if u is None else _f32c(u, "u", (R, I))
             fine = models["fine"]
-            f_f = _field(fine, n_xyz, n_dir, dev)
-            a_emb = t_emb = None
+            cfg["f_f"] = f_f = _field(fine, n_xyz, n_dir, dev)
+            params += [p for _, w, b in f_f.param_list() for p in (w, b)]
             if fine.encode_appearance:
                 a_emb = kwargs["a_embedded"] if "a_embedded" in kwargs else embeddings["a"](ts)
-                a_emb = _f32c(a_emb, "a_embedded", (R, f_f.desc.n_a))
-            use_t = bool(kwargs.get("output_transient", True) and fine.encode_transient)
-            if use_t:
+                if tuple(a_emb.shape) != (R, f_f.desc.n_a):
+                    raise ValueError(f"a_embedded must be ({R}, {f_f.desc.n_a})")
+            cfg["use_t"] = bool(kwargs.get("output_transient", True) and fine.encode_transient)
+            if cfg["use_t"]:
                 t_emb = kwargs["t_embedded"] if "t_embedded" in kwargs else embeddings["t"](ts)
-                t_emb = _f32c(t_emb, "t_embedded", (R, f_f.desc.n_tau))
-            noise_f = None
-            if not use_t:
-                noise_f = kwargs.get("noise_fine")
-                noise_f = torch.randn(R, F, device=dev) if noise_f is None else _f32c(noise_f, "noise_fine", (R, F))
-            of = _run_pass(f_f, rays, F, z=z_fine, noise=noise_f if noise_std != 0 else None, noise_std=noise_std,
-                           a_emb=a_emb, t_emb=t_emb, view_dir=view_dir, white_back=white_back,
-                           test_extras=bool(test_time), field_raw=raw)
-            result["weights_fine"] = of["weights"]
-            result["opacity_fine"] = of["opacity"]
-            if use_t:
-                result["transient_sigmas"] = of["transient_sigmas"]
-                result["beta"] = of["beta"]
-                result["_rgb_fine_static"] = of["rgb_static"]
-                result["_rgb_fine_transient"] = of["rgb_transient"]
-                result["rgb_fine"] = of["rgb"]
-                if test_time:
-                    result["rgb_fine_static"] = of["rgb_static_only"]
-                    result["depth_fine_static"] = of["depth_static_only"]
-                    result["rgb_fine_transient"] = of["rgb_transient_only"]
-                    result["depth_fine_transient"] = of["depth_transient_only"]
+                if tuple(t_emb.shape) != (R, f_f.desc.n_tau):
+                    raise ValueError(f"t_embedded must be ({R}, {f_f.desc.n_tau})")
             else:
-                result["rgb_fine"] = of["rgb"]
-            result["depth_fine"] = of["depth"]
-            if raw:
-                result["_field_raw_fine"] = of["field_raw"]
-                result["_z_fine"] = z_fine
+                nf = kwargs.get("noise_fine")
+                nf = torch.randn(R, F, device=dev) if nf is None else _f32c(nf, "noise_fine", (R, F))
+                cfg["noise_f"] = nf if noise_std != 0 else None
+
+        needs_grad = torch.is_grad_enabled() and (
+            any(p.requires_grad for p in params)
+            or any(t is not None and t.requires_grad for t in (a_emb, t_emb)))
+        if needs_grad:
+            if test_time:
+                raise RuntimeError("test_time=True is an inference mode; call it under torch.no_grad()")
+            outs = _RenderRaysFn.apply(cfg, rays, a_emb, t_emb, *params)
+            keys = [k for k in _result_keys(cfg)]
+            return dict(zip(keys, outs))
+        a_c = None if a_emb is None else _f32c(a_emb, "a_embedded")
+        t_c = None if t_emb is None else _f32c(t_emb, "t_embedded")
+        result, _ = _forward(cfg, rays, a_c, t_c, train=False)
     return result
+
+
+def _result_keys(cfg):
+    keys = ["weights_coarse", "opacity_coarse"]
+    if not cfg["test_time"]:
+        keys += ["rgb_coarse", "depth_coarse"]
+    if cfg["I"] > 0:
+        keys += ["weights_fine", "opacity_fine"]
+        if cfg["use_t"]:
+            keys += ["transient_sigmas", "beta", "_rgb_fine_static", "_rgb_fine_transient", "rgb_fine"]
+            if cfg["test_time"]:
+                keys += ["rgb_fine_static", "depth_fine_static", "rgb_fine_transient", "depth_fine_transient"]
+        else:
+            keys += ["rgb_fine"]
+        keys += ["depth_fine"]
+    return keys
