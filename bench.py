@@ -4,14 +4,20 @@
 Workload (BASELINE.json configs[1]): Blender-lego-like rays (near 2, far 6),
 batch_size = 4096 rays per GPU, N_samples = 64 + N_importance = 64, base NeRF
 coarse + fine, training-mode sampling (perturb = 1, noise_std = 1, white
-background), synthetic rays and seeded random-init weights.  One step = one
-render_rays call on one batch that is already resident in HBM.
+background), synthetic rays/targets and seeded random-init weights, batch already
+resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode render]
+  --mode train  (default) one step = render_rays forward + colour loss (losses.py:35-41)
+                + hand-written backward + gradient all-reduce (N > 1) + Adam step
+                (lr 5e-4, eps 1e-8: utils/__init__.py:30-32) + weight re-pack
+  --mode render one step = render_rays forward only (pack + coarse + sample_pdf + fine)
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|render]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rays shard across ranks with no data-path collective (weak scaling: every rank
-renders its own 4096-ray batch).  Prints ONE JSON line on rank 0.
+renders its own 4096-ray batch); training adds ONE flat RCCL all-reduce of the
+gradients per step.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -71,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", default="render", choices=["render"])
+    ap.add_argument("--mode", default="train", choices=["train", "render"])
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -100,9 +106,25 @@ def main():
     rays = orc.make_rays(R_PER_GPU, 100 + rank).to(dev)       # each rank: its own shard of rays
     ts = torch.zeros(R_PER_GPU, dtype=torch.long, device=dev)
 
-    def step():
+    target = torch.rand(R_PER_GPU, 3, device=dev)
+    params = [p for m in models.values() for p in m.parameters()]
+    opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)
+    from nerf_fl_amd import parallel
+
+    def render_step():
         with torch.no_grad():
             return render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, True, False)
+
+    def train_step():
+        opt.zero_grad(set_to_none=True)
+        res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, True, False)
+        loss = 0.5 * ((res["rgb_coarse"] - target) ** 2).mean() + 0.5 * ((res["rgb_fine"] - target) ** 2).mean()
+        loss.backward()
+        if dist is not None:
+            parallel.all_reduce_gradients(params)
+        opt.step()
+
+    step = train_step if args.mode == "train" else render_step
 
     def sync():
         torch.cuda.synchronize()
@@ -138,11 +160,24 @@ def main():
         "dtype": "f16x3" if args.precision == "f16x3" else "f16",
         "data": "synthetic",
         "config": {"workload": "configs[1]: lego-like rays 4096/GPU, N_samples=64 + N_importance=64, base NeRF "
-                               "coarse+fine, perturb=1 noise_std=1 white_back, forward render_rays (pack + coarse "
-                               "pass + sample_pdf + fine pass)",
+                               "coarse+fine, perturb=1 noise_std=1 white_back; "
+                               + ("train step: render_rays fwd + colour loss + HIP backward + grad all-reduce + Adam"
+                                  if args.mode == "train" else
+                                  "forward render_rays (pack + coarse pass + sample_pdf + fine pass)"),
                    "rays_per_gpu": R_PER_GPU, "mode": args.mode, "precision": args.precision,
                    "mlp_evals_per_ray": N_SAMPLES + N_SAMPLES + N_IMPORTANCE},
     }
+
+    if args.mode == "train":
+        # forward-only throughput of the same batch, reported beside the train-step value
+        for _ in range(3):
+            render_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            render_step()
+        sync()
+        out["render_only_value"] = R_PER_GPU * (N_SAMPLES + N_IMPORTANCE) * world * 20 / (time.perf_counter() - t0)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: the fine-pass launch of nfl_render_kernel

@@ -202,9 +202,12 @@ typedef struct nfl_field_grads {
     float* weight[NFL_NUM_LAYERS];
     float* bias[NFL_NUM_LAYERS];
 } nfl_field_grads;
-int nfl_mlp_wgrad(const nfl_field_desc* desc, const char* d_act_stash, const char* d_grad_stash,
-                  int32_t n_rays, int32_t n_samples, int32_t use_transient,
-                  const nfl_field_grads* grads, void* stream);
+/* wgrad plan: the list of per-layer streaming GEMM jobs (host-built once per field and
+ * transient on/off; the caller uploads it verbatim like the other plans). */
+size_t nfl_wgrad_plan_bytes(void);
+int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, void* h_plan, size_t bytes);
+int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
+                  int32_t n_rays, int32_t n_samples, const nfl_field_grads* grads, void* stream);
 
 /* ---- hierarchical sampling (reference sample_pdf, rendering.py:7-46, plus the
  * concat + sort of rendering.py:267-272) -------------------------------------

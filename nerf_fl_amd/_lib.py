@@ -96,7 +96,9 @@ SYMBOLS = [
     ("nfl_bwd_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc)]),
     ("nfl_composite_backward", C.c_int, [C.POINTER(CompBwdArgs), C.c_void_p]),
     ("nfl_mlp_dgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DgradArgs), C.c_void_p]),
-    ("nfl_mlp_wgrad", C.c_int, [C.POINTER(FieldDesc), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+    ("nfl_wgrad_plan_bytes", C.c_size_t, []),
+    ("nfl_wgrad_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),
+    ("nfl_mlp_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                 C.POINTER(FieldGrads), C.c_void_p]),
     ("nfl_abi_version", C.c_int, []),
     ("nfl_version", C.c_char_p, []),

@@ -29,7 +29,6 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #define WG_MAX_OT 8      // out tiles (32 features) per job
 #define WG_MAX_IT 11     // in tiles per job
 #define WG_NOT 2         // out tiles per wave
-#define WG_MAXPW 10      // 1 KiB DMA pieces per wave per segment
 #define WG_SLOT (2048 * (WG_MAX_OT + WG_MAX_IT))
 
 struct WgTile {
@@ -48,14 +47,21 @@ struct WgJob {
     WgTile ot[WG_MAX_OT];
     WgTile it[WG_MAX_IT];
 };
+#define WG_MAX_JOBS 20
+struct WgPlan {          // host-built once per (field, transient on/off); the caller keeps a device copy
+    uint32_t magic;
+    int32_t n_jobs;
+    int32_t act_slots, grd_slots;
+    int32_t cost[WG_MAX_JOBS];     // DMA pieces per wave per segment (4 / 5 / 8): the job's relative cost
+    WgJob job[WG_MAX_JOBS];
+};
 struct WgArgs {
+    const WgPlan* plan;  // device
     const char* act;     // activation stash
     const char* grd;     // gradient stash
-    int act_slots, grd_slots;
-    int n_seg, seg_per_wg;
+    int n_seg;
+    int wg_start[WG_MAX_JOBS + 1];   // workgroups [wg_start[j], wg_start[j+1]) work on job j
     nfl_field_grads g;
-    int n_jobs;
-    WgJob job[10];
 };
 
 __device__ __forceinline__ int wg_orig(int kind, int i) {
@@ -83,36 +89,33 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
     }
 }
 
-__global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const WgJob& J = A.job[blockIdx.y];
+template <int PW>
+__device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const int act_slots, const int grd_slots,
+                                        const int seg0, const int seg1, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave % J.n_wo, wi = wave / J.n_wo;
-    int seg0 = blockIdx.x * A.seg_per_wg, seg1 = seg0 + A.seg_per_wg;
-    if (seg1 > A.n_seg) seg1 = A.n_seg;
-    if (seg0 >= seg1) return;
     const int n_pieces = 2 * (J.n_ot + J.n_it);
 
     // this wave's DMA pieces: source base (+ lane*16), per-segment stride, LDS offset
-    const char* psrc[WG_MAXPW];
-    size_t pstride[WG_MAXPW];
-    int pdst[WG_MAXPW];
+    const char* psrc[PW];
+    size_t pstride[PW];
+    int pdst[PW];
 #pragma unroll
-    for (int pp = 0; pp < WG_MAXPW; ++pp) {
+    for (int pp = 0; pp < PW; ++pp) {
         int p = wave + 4 * pp;
         p = p < n_pieces ? p : n_pieces - 1;
         const int t = p >> 1;
         const bool is_out = t < J.n_ot;
         const int slot = (is_out ? J.ot[t].slot : J.it[t - J.n_ot].slot) + (p & 1);
         psrc[pp] = (is_out ? A.grd : A.act) + (size_t)slot * 1024 + lane * 16;
-        pstride[pp] = (size_t)(is_out ? A.grd_slots : A.act_slots) * 1024;
+        pstride[pp] = (size_t)(is_out ? grd_slots : act_slots) * 1024;
         pdst[pp] = p * 1024;
     }
     auto issue = [&](int seg, int s) __attribute__((always_inline)) {
         const int sg = seg < seg1 ? seg : seg1 - 1;          // surplus issues re-read the last segment
 #pragma unroll
-        for (int pp = 0; pp < WG_MAXPW; ++pp)
+        for (int pp = 0; pp < PW; ++pp)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(psrc[pp] + (size_t)sg * pstride[pp]),
                 (__attribute__((address_space(3))) void*)(smem + s * WG_SLOT + pdst[pp]), 16, 0, 0);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     issue(seg0 + 1, 1);
     int s_read = 0, s_issue = 2;
     for (int seg = seg0; seg < seg1; ++seg) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WG_MAXPW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         issue(seg + 2, s_issue);
@@ -202,6 +205,22 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     }
 }
 
+__global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WgPlan& P = *A.plan;
+    int j = 0;
+    while (j + 1 < P.n_jobs && (int)blockIdx.x >= A.wg_start[j + 1]) ++j;
+    const int part = blockIdx.x - A.wg_start[j], nparts = A.wg_start[j + 1] - A.wg_start[j];
+    const int seg0 = (int)((long long)A.n_seg * part / nparts);
+    const int seg1 = (int)((long long)A.n_seg * (part + 1) / nparts);
+    if (seg0 >= seg1) return;
+    const WgJob& J = P.job[j];
+    const int pw = P.cost[j];
+    if (pw <= 4) wg_body<4>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+    else if (pw <= 5) wg_body<5>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+    else wg_body<8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+}
+
 // ---------------------------------------------------------------------------------
 static void add_tiles(WgTile* dst, int& n, int slot0, int kind, int idx0, int count) {
     for (int t = 0; 32 * t < count; ++t) {
@@ -228,27 +247,27 @@ static void finish_job(WgJob& j) {
     else { j.n_wo = 1; j.n_wi = 4; }                     // heads: split the in tiles
 }
 
-extern "C" int nfl_mlp_wgrad(const nfl_field_desc* d, const char* d_act_stash, const char* d_grad_stash,
-                             int32_t n_rays, int32_t n_samples, int32_t use_transient,
-                             const nfl_field_grads* grads, void* stream) {
+extern "C" size_t nfl_wgrad_plan_bytes(void) { return sizeof(WgPlan); }
+
+extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transient, void* h_plan, size_t bytes) {
     NflPlan p;
-    if (!d || !d_act_stash || !d_grad_stash || !grads) return NFL_EINVAL;
+    if (!d || !h_plan) return NFL_EINVAL;
+    if (bytes < sizeof(WgPlan)) return NFL_ESMALL;
     if (nfl_plan_fill(d, NFL_PREC_F16X3, &p) != NFL_OK) return NFL_EINVAL;
-    if (n_rays < 0 || n_samples < 1) return NFL_EINVAL;
-    if (n_rays == 0) return NFL_OK;
     const int nkp = p.nkp, cx = 6 * d->n_emb_xyz + 3, W = NFL_W, H = NFL_W / 2;
     const bool ut = p.has_t && use_transient;
-    WgArgs A;             // kernel argument block, built on the host each call
-    memset(&A, 0, sizeof(A));
-    WgJob jobs[24];
-    A.act = d_act_stash;
-    A.grd = d_grad_stash;
-    A.act_slots = nfl_act_slots(nkp);
-    A.grd_slots = NFL_GRD_SLOTS;
-    A.n_seg = n_rays * ((n_samples + 31) / 32);
-    A.g = *grads;
+    WgPlan& P = *static_cast<WgPlan*>(h_plan);
+    memset(&P, 0, sizeof(P));
+    P.magic = NFL_PLAN_MAGIC ^ 0x57u;
+    P.act_slots = nfl_act_slots(nkp);
+    P.grd_slots = NFL_GRD_SLOTS;
     int nj = 0;
-    auto push = [&](WgJob j) { finish_job(j); jobs[nj++] = j; };
+    auto push = [&](WgJob j) {
+        finish_job(j);
+        const int pw = (2 * (j.n_ot + j.n_it) + 3) / 4;
+        P.cost[nj] = pw <= 4 ? 4 : (pw <= 5 ? 5 : 8);
+        P.job[nj++] = j;
+    };
     for (int l = 1; l <= 8; ++l) {
         WgJob j = make_job(NFL_P_XYZ1 + l - 1, p.ld[NFL_P_XYZ1 + l - 1], true);
         add_tiles(j.ot, j.n_ot, NFL_GRD_D(l), NFL_SEG_ACT, 0, W);
@@ -317,15 +336,41 @@ extern "C" int nfl_mlp_wgrad(const nfl_field_desc* d, const char* d_act_stash, c
             push(j);
         }
     }
-    A.n_jobs = nj;
-    // K split: enough workgroups to fill the chip about twice
+    P.n_jobs = nj;
+    return NFL_OK;
+}
+
+extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash,
+                             const char* d_grad_stash, int32_t n_rays, int32_t n_samples,
+                             const nfl_field_grads* grads, void* stream) {
+    const WgPlan* hp = static_cast<const WgPlan*>(h_wplan);
+    if (!hp || hp->magic != (NFL_PLAN_MAGIC ^ 0x57u) || !d_wplan || !d_act_stash || !d_grad_stash || !grads)
+        return NFL_EINVAL;
+    if (n_rays < 0 || n_samples < 1) return NFL_EINVAL;
+    if (n_rays == 0) return NFL_OK;
+    WgArgs A;
+    memset(&A, 0, sizeof(A));
+    A.plan = static_cast<const WgPlan*>(d_wplan);
+    A.act = d_act_stash;
+    A.grd = d_grad_stash;
+    A.n_seg = n_rays * ((n_samples + 31) / 32);
+    A.g = *grads;
+    // two workgroups' worth of work per CU, dealt to the jobs in proportion to their streamed bytes
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    int nsplit = (2 * ncu + nj - 1) / nj;
-    if (nsplit > A.n_seg) nsplit = A.n_seg;
-    if (nsplit < 1) nsplit = 1;
-    A.seg_per_wg = (A.n_seg + nsplit - 1) / nsplit;
-    nsplit = (A.n_seg + A.seg_per_wg - 1) / A.seg_per_wg;
+    const int nj = hp->n_jobs;
+    int total_cost = 0;
+    for (int j = 0; j < nj; ++j) total_cost += hp->cost[j];
+    const int budget = 2 * ncu;
+    int acc_wg = 0;
+    for (int j = 0; j < nj; ++j) {
+        int n = (int)((long long)budget * hp->cost[j] / total_cost);
+        if (n < 1) n = 1;
+        if (n > A.n_seg) n = A.n_seg;
+        A.wg_start[j] = acc_wg;
+        acc_wg += n;
+    }
+    A.wg_start[nj] = acc_wg;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel),
@@ -333,11 +378,6 @@ extern "C" int nfl_mlp_wgrad(const nfl_field_desc* d, const char* d_act_stash, c
             return NFL_ENODEV;
         attr_set = true;
     }
-    for (int j0 = 0; j0 < nj; j0 += 10) {       // the argument block holds 10 jobs (< 4 KiB of kernel arguments)
-        const int n = nj - j0 < 10 ? nj - j0 : 10;
-        memcpy(A.job, jobs + j0, n * sizeof(WgJob));
-        A.n_jobs = n;
-        hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(nsplit, n), dim3(256), 3 * WG_SLOT, static_cast<hipStream_t>(stream), A);
-    }
+    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 3 * WG_SLOT, static_cast<hipStream_t>(stream), A);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

@@ -92,6 +92,16 @@ class _PackedField:
         # dgrad stream (transposed weights, bf16 hi+lo); built lazily on the first training forward
         self.h_bplan = self.d_bplan = self.bpacked = None
         self.bkey = None
+        self.wplans = {}          # use_transient -> (host blob, device copy) of the wgrad job list
+
+    def wgrad_plan(self, use_t):
+        if use_t not in self.wplans:
+            L = _lib.lib()
+            n = L.nfl_wgrad_plan_bytes()
+            h = C.create_string_buffer(n)
+            _lib.check(L.nfl_wgrad_plan_build(C.byref(self.desc), int(use_t), h, n), "nfl_wgrad_plan_build")
+            self.wplans[use_t] = (h, torch.frombuffer(bytearray(h.raw), dtype=torch.uint8).to(self.device))
+        return self.wplans[use_t]
 
     def param_list(self):
         """(layer index, weight, bias) for every layer this field has, in NFL_P_* order."""
@@ -329,8 +339,9 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents):
         off += b.numel()
         fg.weight[i], fg.bias[i] = gw.data_ptr(), gb.data_ptr()
         views += [gw, gb]
-    _lib.check(L.nfl_mlp_wgrad(C.byref(field.desc), _ptr(st["act"]), _ptr(grad_stash), R, N, int(use_t),
-                               C.byref(fg), _stream()), "nfl_mlp_wgrad")
+    h_wp, d_wp = field.wgrad_plan(use_t)
+    _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), R, N, C.byref(fg), _stream()),
+               "nfl_mlp_wgrad")
     return views, g_a, g_t
 
 
@@ -344,8 +355,10 @@ class _RenderRaysFn(torch.autograd.Function):
         result, saved = _forward(cfg, rays, None if a_emb is None else _f32c(a_emb, "a_embedded"),
                                  None if t_emb is None else _f32c(t_emb, "t_embedded"), train=True)
         cfg["f_c"].ensure_bwd_packed()
+        cfg["f_c"].wgrad_plan(False)
         if cfg["f_f"] is not None:
             cfg["f_f"].ensure_bwd_packed()
+            cfg["f_f"].wgrad_plan(cfg["use_t"])
         keys = [k for k in result if not k.startswith("_field_raw") and k != "_z_fine"]
         ctx.cfg, ctx.keys, ctx.saved, ctx.rays = cfg, keys, saved, rays
         ctx.a_emb, ctx.t_emb = a_emb, t_emb
