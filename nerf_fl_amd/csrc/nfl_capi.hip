@@ -44,7 +44,7 @@ size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_sa
 }
 size_t nfl_grad_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples) {
     if (!d || n_rays < 0 || n_samples < 1) return 0;
-    return n_segments(n_rays, n_samples) * NFL_GRD_SLOTS * 1024 + 4096;
+    return (n_segments(n_rays, n_samples) + 1) * NFL_GRD_SLOTS * 1024 + 4096;   // + one scratch record for padded segments
 }
 int nfl_bwd_plan_build(const nfl_field_desc* desc, void* h_plan, size_t bytes) {
     if (!h_plan) return NFL_EINVAL;
@@ -87,8 +87,8 @@ const char* nfl_strerror(int code) {
 }
 
 const char* nfl_render_kernel_name(int prec, int n_emb_xyz) {
-    if (prec == NFL_PREC_F16X3) return n_emb_xyz == 15 ? "nfl_render_kernel<3, 1, 15>" : "nfl_render_kernel<3, 1, 10>";
-    return n_emb_xyz == 15 ? "nfl_render_kernel<1, 1, 15>" : "nfl_render_kernel<1, 1, 10>";
+    if (prec == NFL_PREC_F16X3) return n_emb_xyz == 15 ? "nfl_render_kernel<3, 1, 15, false>" : "nfl_render_kernel<3, 1, 10, false>";
+    return n_emb_xyz == 15 ? "nfl_render_kernel<1, 1, 15, false>" : "nfl_render_kernel<1, 1, 10, false>";
 }
 
 }  // extern "C"

@@ -21,7 +21,7 @@ struct DgradArgs {
     nfl_dgrad_args a;
     int n_chunks, c_start;
     int has_a, has_t, use_t;
-    int spr, rays_per_wg, nkp;
+    int spr, rays_per_wg, nkp, n_seg_total;
 };
 
 template <int NFX>
@@ -38,39 +38,33 @@ struct NflDgradCfg {
     static constexpr int LDS_BYTES = LDS_TAB + 3 * SLOT;
 };
 
-// ring with the per-wave mask pieces
-template <int SLOT_BYTES, int WBYTES, int MAXP>
+// ring with the per-wave mask pieces: pieces 0..MAXPW-1 are weights, MAXPW and MAXPW+1 the 2 KiB
+// of this wave's activation-stash slice that carries the relu mask of the tile
+template <int SLOT_BYTES, int WBYTES, int MAXPW>
 struct NflRingAux {
+    static constexpr int MAXP = MAXPW + 2;
     const char* gsrc;
     const int* chunk_off;
     const int* chunk_aux;
     char* lds;
-    const char* aux_src;      // activation stash + lane*16
+    const char* aux_src;      // activation stash (wave-uniform base)
     size_t seg_stride;        // bytes per segment record
     int n_chunks, c_start, c_issue, s_issue, s_read;
     int seg_issue, seg_last;  // this wave's (clamped) global segment for the tile c_issue belongs to
     int wave, lane;
+    const char* i_src;
+    const char* i_aux;
+    char* i_dst;
+    int i_nbytes;
 
-    NFL_DEV void issue() {
+    NFL_DEV void begin_issue() {
         const int off0 = chunk_off[c_issue];
-        const int nbytes = chunk_off[c_issue + 1] - off0;
-        const char* src = gsrc + off0 + lane * 16;
-        char* dst = lds + s_issue * SLOT_BYTES;
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) {
-            int byte = (wave + 4 * p) * 1024;
-            byte = byte < nbytes ? byte : nbytes - 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + byte),
-                                             (__attribute__((address_space(3))) void*)(dst + byte), 16, 0, 0);
-        }
+        i_nbytes = chunk_off[c_issue + 1] - off0;
+        i_src = gsrc + off0;
+        i_dst = lds + s_issue * SLOT_BYTES;
         int slot = chunk_aux[c_issue];
         slot = slot < 0 ? 0 : slot;
-        const char* ms = aux_src + (size_t)seg_issue * seg_stride + slot * 1024;
-        char* md = dst + WBYTES + wave * 2048;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ms,
-                                         (__attribute__((address_space(3))) void*)md, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ms + 1024),
-                                         (__attribute__((address_space(3))) void*)(md + 1024), 16, 0, 0);
+        i_aux = aux_src + (size_t)seg_issue * seg_stride + slot * 1024;
         if (c_issue + 1 == n_chunks) {
             c_issue = c_start;
             seg_issue = seg_issue + 4 < seg_last ? seg_issue + 4 : seg_last;
@@ -79,12 +73,36 @@ struct NflRingAux {
         }
         s_issue = s_issue == 2 ? 0 : s_issue + 1;
     }
+    template <int P>
+    NFL_DEV void piece() {
+        if constexpr (P < MAXPW) {
+            int byte = (wave + 4 * P) * 1024;
+            byte = byte < i_nbytes ? byte : i_nbytes - 1024;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(i_src + byte + (threadIdx.x & 63) * 16),
+                (__attribute__((address_space(3))) void*)(i_dst + byte), 16, 0, 0);
+        } else if constexpr (P < MAXP) {
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(i_aux + (P - MAXPW) * 1024 + (threadIdx.x & 63) * 16),
+                (__attribute__((address_space(3))) void*)(i_dst + WBYTES + wave * 2048 + (P - MAXPW) * 1024), 16, 0, 0);
+        }
+    }
+    template <int P0, int P1>
+    NFL_DEV void pieces() {
+        nfl_static_for<P0, P1>([&](auto P) __attribute__((always_inline)) { piece<decltype(P)::value>(); });
+    }
+    NFL_DEV void prime() {
+        begin_issue();
+        pieces<0, MAXP>();
+        begin_issue();
+        pieces<0, MAXP>();
+    }
     NFL_DEV const char* consume() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 2) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue();
-        const char* base = lds + s_read * SLOT_BYTES + lane * 16;
+        begin_issue();
+        const char* base = lds + s_read * SLOT_BYTES + (threadIdx.x & 63) * 16;
         s_read = s_read == 2 ? 0 : s_read + 1;
         return base;
     }
@@ -95,21 +113,45 @@ NFL_DEV void dg_zero(f16v (&acc)[1]) {
     for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
 }
 
-// accumulator tile -> masked, split, stored into the next operand set and the gradient stash
+// epilogue of a dgrad tile, cut into 8 pair-ops: relu mask (sign of the stashed activation),
+// bf16 hi+lo split into the next operand set, bf16 copy into the gradient stash
 template <bool MASK, int NOUT>
-NFL_DEV void dg_store(const f16v (&acc)[1], const b8 (&mk)[2], b8 (&out)[NOUT][1][2], int ks, char* gst, int slot) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = acc[0][8 * s + j];
-            v[j] = MASK ? ((float)mk[s][j] > 0.f ? x : 0.f) : x;
+struct DgEpi {
+    const f16v (&acc)[1];
+    const b8 (&mk)[2];
+    b8 (&out)[NOUT][1][2];
+    const int ks;
+    char* const gst;
+    const int slot;
+    b8 tmp;
+
+    template <int OP>
+    NFL_DEV void pair() {
+        constexpr int s = OP / 4, j = 2 * (OP % 4);
+        float x0 = acc[0][8 * s + j], x1 = acc[0][8 * s + j + 1];
+        if (MASK) {
+            x0 = (float)mk[s][j] > 0.f ? x0 : 0.f;
+            x1 = (float)mk[s][j + 1] > 0.f ? x1 : 0.f;
         }
-        nfl_split8<2>(v, out[ks + s][0]);
-        if (gst) nfl_stash8(v, gst + (slot + s) * 1024);
+        const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+        out[ks + s][0][0][j] = h0;
+        out[ks + s][0][0][j + 1] = h1;
+        out[ks + s][0][1][j] = (__bf16)(x0 - (float)h0);
+        out[ks + s][0][1][j + 1] = (__bf16)(x1 - (float)h1);
+        tmp[j] = h0;
+        tmp[j + 1] = h1;
+        if (OP % 4 == 3) *reinterpret_cast<b8*>(gst + (slot + s) * 1024) = tmp;
     }
-}
+    template <int K, int NK>
+    NFL_DEV void step() {
+        nfl_static_for<(8 * K) / NK, (8 * (K + 1)) / NK>([&](auto O) __attribute__((always_inline)) {
+            pair<decltype(O)::value>();
+        });
+    }
+    NFL_DEV void all() {
+        nfl_static_for<0, 8>([&](auto O) __attribute__((always_inline)) { pair<decltype(O)::value>(); });
+    }
+};
 
 // NRT transposed row tiles (one per chunk) with up to three K segments
 template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NA, int NB, int NC, int NOUT, class Ring>
@@ -117,22 +159,34 @@ NFL_DEV void dg_tiles(Ring& ring, int wave,
                       const b8 (&inA)[NA][1][2], int ksA, const b8 (&inB)[NB][1][2], int ksB,
                       const b8 (&inC)[NC][1][2], int ksC,
                       b8 (&out)[NOUT][1][2], int out_ks0, char* gst, int slot0) {
+    constexpr int NK = NKA + NKB + NKC;
     f16v acc[2][1];
     b8 mk[2][2];
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const b8& {
+        constexpr int k = decltype(K)::value;
+        if constexpr (k < NKA) return inA[ksA + k][0][part];
+        else if constexpr (k < NKA + NKB) return inB[ksB + k - NKA][0][part];
+        else return inC[ksC + k - NKA - NKB][0][part];
+    };
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const char* wl = ring.consume();
         dg_zero(acc[i & 1]);
-        nfl_mma<2, 1, NKA, NA>(acc[i & 1], inA, ksA, wl, 0);
-        if (NKB > 0) nfl_mma<2, 1, NKB, NB>(acc[i & 1], inB, ksB, wl, NKA);
-        if (NKC > 0) nfl_mma<2, 1, NKC, NC>(acc[i & 1], inC, ksC, wl, NKA + NKB);
-        if (MASK) {
+        if (MASK) {      // the slot is recycled at the next consume(): take the mask now
             mk[i & 1][0] = *reinterpret_cast<const b8*>(wl + WB + wave * 2048);
             mk[i & 1][1] = *reinterpret_cast<const b8*>(wl + WB + wave * 2048 + 1024);
         }
-        if (i > 0) dg_store<MASK, NOUT>(acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1));
+        if constexpr (i > 0) {
+            DgEpi<MASK, NOUT> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
+            nfl_tile<2, 1, NK, 0, b8>(acc[i & 1], wl, 0, getb, epi, ring);
+        } else {
+            NflNoEpi epi;
+            nfl_tile<2, 1, NK, 0, b8>(acc[i & 1], wl, 0, getb, epi, ring);
+        }
+        ring.template pieces<NK, Ring::MAXP>();
     });
-    dg_store<MASK, NOUT>(acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1));
+    DgEpi<MASK, NOUT> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
+    last.all();
 }
 
 // one tile whose rows are latent inputs: sum over the 32 samples of the segment, add to the ray's gradient
@@ -141,7 +195,12 @@ NFL_DEV void dg_latent_tile(Ring& ring, const b8 (&in)[NIN][1][2], int ks0, floa
     const char* wl = ring.consume();
     f16v acc[1];
     dg_zero(acc);
-    nfl_mma<2, 1, NK, NIN>(acc, in, ks0, wl, 0);
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const b8& {
+        return in[ks0 + decltype(K)::value][0][part];
+    };
+    NflNoEpi epi;
+    nfl_tile<2, 1, NK, 0, b8>(acc, wl, 0, getb, epi, ring);
+    ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float s = nfl_sum32(acc[0][r]);
@@ -181,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     ring.chunk_off = chk_lds;
     ring.chunk_aux = aux_lds;
     ring.lds = smem + C::LDS_TAB;
-    ring.aux_src = a.d_act_stash + lane * 16;
+    ring.aux_src = a.d_act_stash;
     ring.seg_stride = (size_t)nfl_act_slots(NKP) * 1024;
     ring.n_chunks = A.n_chunks;
     ring.c_start = A.c_start;
@@ -192,8 +251,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     ring.seg_issue = ray0 * SPR + wave < ring.seg_last ? ray0 * SPR + wave : ring.seg_last;
     ring.wave = wave;
     ring.lane = lane;
-    ring.issue();
-    ring.issue();
+    ring.prime();
 
     for (int tile = 0; tile < ntiles; ++tile) {
         const int g = tile * 4 + wave;
@@ -202,7 +260,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         const int ray = ray0 + gg / SPR;
         const int i = (gg % SPR) * 32 + c;
         const bool ok = seg_ok && i < N;
-        char* gst = seg_ok ? a.d_grad_stash + (size_t)(ray0 * SPR + gg) * NFL_GRD_SLOTS * 1024 + lane * 16 : nullptr;
+        // padded segments (zero gradients) write to a scratch record past the end: no branch in the epilogue
+        char* gst = a.d_grad_stash + (size_t)(seg_ok ? ray0 * SPR + gg : A.n_seg_total) * NFL_GRD_SLOTS * 1024 + lane * 16;
 
         float hg[9];
         {
@@ -223,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             nfl_split8<2>(vTs, dTs[0][0]);
             nfl_split8<2>(vTc, dTc[0][0]);
             nfl_split8<2>(vTb, dTb[0][0]);
-            if (gst) {
+            {
                 nfl_stash8(vS, gst + (NFL_GRD_HEADS + 0) * 1024);
                 nfl_stash8(vC, gst + (NFL_GRD_HEADS + 1) * 1024);
                 nfl_stash8(vTs, gst + (NFL_GRD_HEADS + 2) * 1024);
@@ -276,6 +335,7 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     A.c_start = (hp->has_t && !A.use_t) ? 17 : 0;
     A.spr = (args->n_samples + 31) / 32;
     A.nkp = hp->nkp;
+    A.n_seg_total = args->n_rays * A.spr;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int rpw = (args->n_rays + ncu - 1) / ncu;

@@ -167,8 +167,9 @@ NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th
 // ---------------------------------------------------------------------------------
 // weight ring: global -> LDS by LDS-DMA, 3 slots, prefetch distance 2
 // ---------------------------------------------------------------------------------
-template <int SLOT_BYTES, int MAXP>
+template <int SLOT_BYTES, int MAXP_>
 struct NflRing {
+    static constexpr int MAXP = MAXP_;     // DMA pieces (1 KiB per wave-instruction) every wave issues per chunk
     const char* gsrc;
     const int* chunk_off;
     char* lds;          // ring base (LDS)
@@ -177,36 +178,49 @@ struct NflRing {
     int s_issue;        // slot it goes to
     int s_read;         // slot of the next chunk to consume
     int wave, lane;
+    // chunk currently being issued (pieces are spread over the MFMA loop of the chunk being consumed)
+    const char* i_src;
+    char* i_dst;
+    int i_nbytes;
 
-    NFL_DEV void issue() {
+    NFL_DEV void begin_issue() {
         const int off0 = chunk_off[c_issue];
-        const int nbytes = chunk_off[c_issue + 1] - off0;
-        const char* src = gsrc + off0 + lane * 16;
-        char* dst = lds + s_issue * SLOT_BYTES;
-#pragma unroll
-        for (int p = 0; p < MAXP; ++p) {
-            int byte = (wave + 4 * p) * 1024;
-            byte = byte < nbytes ? byte : nbytes - 1024;       // surplus pieces re-copy the last KiB
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(src + byte),
-                (__attribute__((address_space(3))) void*)(dst + byte), 16, 0, 0);
-        }
+        i_nbytes = chunk_off[c_issue + 1] - off0;
+        i_src = gsrc + off0;                 // wave-uniform; the lane offset is added per piece (keeps no 64-bit VGPR live)
+        i_dst = lds + s_issue * SLOT_BYTES;
         c_issue = c_issue + 1 == n_chunks ? 0 : c_issue + 1;
         s_issue = s_issue == 2 ? 0 : s_issue + 1;
     }
-    NFL_DEV void prime() {
-        issue();
-        issue();
+    template <int P>
+    NFL_DEV void piece() {
+        if constexpr (P < MAXP) {
+            int byte = (wave + 4 * P) * 1024;
+            byte = byte < i_nbytes ? byte : i_nbytes - 1024;       // surplus pieces re-copy the last KiB
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(i_src + byte + (threadIdx.x & 63) * 16),
+                (__attribute__((address_space(3))) void*)(i_dst + byte), 16, 0, 0);
+        }
     }
-    // Wait for the oldest chunk in flight, make it visible to all waves, refill the slot
-    // that everybody has just finished reading, and return this lane's read base.
+    template <int P0, int P1>
+    NFL_DEV void pieces() {                 // pieces [P0, P1)
+        nfl_static_for<P0, P1>([&](auto P) __attribute__((always_inline)) { piece<decltype(P)::value>(); });
+    }
+    NFL_DEV void prime() {
+        begin_issue();
+        pieces<0, MAXP>();
+        begin_issue();
+        pieces<0, MAXP>();
+    }
+    // Wait for the oldest chunk in flight, make it visible to all waves and return this lane's
+    // read base; the caller then issues the MAXP pieces of the next chunk (piece<P>()) while it
+    // computes, into the slot everybody has just finished reading.
     NFL_DEV const char* consume() {
         // all but the MAXP youngest VMEM ops (= the younger chunk's pieces) are done
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue();
-        const char* base = lds + s_read * SLOT_BYTES + lane * 16;
+        begin_issue();
+        const char* base = lds + s_read * SLOT_BYTES + (threadIdx.x & 63) * 16;
         s_read = s_read == 2 ? 0 : s_read + 1;
         return base;
     }
@@ -230,64 +244,130 @@ NFL_DEV void nfl_bias_init(f16v (&acc)[NCB], const float* bias_rt, int h) {
     }
 }
 
-// acc += W[frag0 .. frag0+NK) * in[ks0 .. ks0+NK)
-template <int NP, int NCB, int NK, int NIN, class V8>
-NFL_DEV void nfl_mma(f16v (&acc)[NCB], const V8 (&in)[NIN][NCB][NP], int ks0, const char* wl, int frag0) {
+// One row tile, software-pipelined in source order.  Every MFMA is followed by a few
+// "fillers" that fit in the issue slots it leaves free (an MFMA holds the issue port for 8 of
+// its 32 cycles): the LDS reads of k-step k+2, one LDS-DMA piece of the chunk being prefetched,
+// and a slice of the PREVIOUS tile's VALU epilogue.  sched_barrier(0) after each micro-slice
+// pins that order (hipcc otherwise emits the DMA pieces and the epilogue back to back after
+// the barrier, with the matrix pipe idle).
+//   getb(K, cb, part) -> B operand of k-step K;  epi.template step<K, NK>() runs the epilogue
+//   work assigned to k-step K;  pieces P0+k are issued at k-step k.
+template <int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring>
+NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& getb, Epi&& epi, Ring& ring) {
     constexpr int KSB = 1024 * NP;
+    V8 w[3][NP];
+    auto load = [&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
+        w[k % 3][0] = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB);
+        if (NP == 2) w[k % 3][NP - 1] = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB + 1024);
+    };
+    load(std::integral_constant<int, 0>{});
+    if constexpr (NK > 1) load(std::integral_constant<int, 1>{});
+    nfl_static_for<0, NK>([&](auto K) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value;
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        const V8 whi = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB);
-        if (NP == 2) {
-            const V8 wlo = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB + 1024);
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                acc[cb] = nfl_mfma(wlo, in[ks0 + k][cb][0], acc[cb]);
-                acc[cb] = nfl_mfma(whi, in[ks0 + k][cb][NP - 1], acc[cb]);
+        for (int cb = 0; cb < NCB; ++cb) {
+            if (NP == 2) {
+                acc[cb] = nfl_mfma(w[k % 3][NP - 1], getb(K, cb, 0), acc[cb]);
+                if (cb == 0) {
+                    if constexpr (k + 2 < NK) load(std::integral_constant<int, k + 2>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[cb] = nfl_mfma(w[k % 3][0], getb(K, cb, NP - 1), acc[cb]);
+                if (cb == 0) ring.template piece<P0 + k>();
+                __builtin_amdgcn_sched_barrier(0);
             }
+            acc[cb] = nfl_mfma(w[k % 3][0], getb(K, cb, 0), acc[cb]);
+            if (NP == 1 && cb == 0) {
+                if constexpr (k + 2 < NK) load(std::integral_constant<int, k + 2>{});
+                ring.template piece<P0 + k>();
+            }
+            if (cb == NCB - 1) epi.template step<k, NK>();
+            __builtin_amdgcn_sched_barrier(0);
         }
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) acc[cb] = nfl_mfma(whi, in[ks0 + k][cb][0], acc[cb]);
-    }
+    });
 }
 
-// accumulator tile -> the two k-steps (2*tile, 2*tile+1) of the next layer's B operand
-template <int NP, int NCB, bool RELU, int NOUT>
-NFL_DEV void nfl_store_act(const f16v (&acc)[NCB], h8 (&out)[NOUT][NCB][NP], int ks,
-                           char* const (&stash)[NCB], int slot) {
+struct NflNoEpi {
+    template <int K, int NK> NFL_DEV void step() {}
+};
+
+// Epilogue of an accumulator tile -> the two k-steps (ks, ks+1) of the next layer's B operand
+// (and, in the training forward, the bf16 activation stash), cut into 8 pair-ops per column
+// block so it can be spread over the k-steps of the following tile.
+template <int NP, int NCB, bool RELU, bool STASH, int NOUT>
+struct NflActEpi {
+    const f16v (&acc)[NCB];
+    h8 (&out)[NOUT][NCB][NP];
+    const int ks;
+    char* const (&stash)[NCB];
+    const int slot;
+    b8 tmp[NCB];
+
+    template <int OP>
+    NFL_DEV void pair() {                      // OP 0..7: elements 2*OP, 2*OP+1 of the 16 accumulators
+        constexpr int s = OP / 4, j = 2 * (OP % 4);
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = acc[cb][8 * s + j];
-                v[j] = RELU ? fmaxf(x, 0.f) : x;
+        for (int cb = 0; cb < NCB; ++cb) {
+            float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
+            if (RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+            const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+            out[ks + s][cb][0][j] = h0;
+            out[ks + s][cb][0][j + 1] = h1;
+            if (NP == 2) {
+                out[ks + s][cb][NP - 1][j] = (_Float16)(x0 - (float)h0);
+                out[ks + s][cb][NP - 1][j + 1] = (_Float16)(x1 - (float)h1);
             }
-            nfl_split8<NP>(v, out[ks + s][cb]);
-            if (stash[cb]) nfl_stash8(v, stash[cb] + (slot + s) * 1024);
+            if (STASH) {
+                tmp[cb][j] = (__bf16)x0;
+                tmp[cb][j + 1] = (__bf16)x1;
+                if (OP % 4 == 3) *reinterpret_cast<b8*>(stash[cb] + (slot + s) * 1024) = tmp[cb];
+            }
         }
-}
+    }
+    template <int K, int NK>
+    NFL_DEV void step() {                      // pair-ops [8K/NK, 8(K+1)/NK)
+        nfl_static_for<(8 * K) / NK, (8 * (K + 1)) / NK>([&](auto O) __attribute__((always_inline)) {
+            pair<decltype(O)::value>();
+        });
+    }
+    NFL_DEV void all() {
+        nfl_static_for<0, 8>([&](auto O) __attribute__((always_inline)) { pair<decltype(O)::value>(); });
+    }
+};
 
 // A dense layer of NRT row tiles reading inA[ksA0..+NKA) then inB[ksB0..+NKB), TPC tiles per
-// ring chunk.  The epilogue of tile i-1 is issued after the MFMAs of tile i so the two overlap.
-template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, int NINA, int NINB, int NOUT, class Ring>
+// ring chunk.  The epilogue of tile i-1 rides in the MFMA shadows of tile i.
+template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool STASH, int NINA, int NINB, int NOUT, class Ring>
 NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
                        const h8 (&inA)[NINA][NCB][NP], int ksA0,
                        const h8 (&inB)[NINB][NCB][NP], int ksB0,
                        h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&stash)[NCB], int slot0) {
+    constexpr int NK = NKA + NKB;
     f16v acc[2][NCB];
     const char* wl = nullptr;
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
+        constexpr int k = decltype(K)::value;
+        if constexpr (k < NKA) return inA[ksA0 + k][cb][part];
+        else return inB[ksB0 + k - NKA][cb][part];
+    };
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         if (i % TPC == 0) wl = ring.consume();
-        constexpr int frag0 = (i % TPC) * (NKA + NKB);
+        constexpr int frag0 = (i % TPC) * NK;
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
-        nfl_mma<NP, NCB, NKA, NINA>(acc[i & 1], inA, ksA0, wl, frag0);
-        if (NKB > 0) nfl_mma<NP, NCB, NKB, NINB>(acc[i & 1], inB, ksB0, wl, frag0 + NKA);
-        if (i > 0) nfl_store_act<NP, NCB, RELU, NOUT>(acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1));
+        if constexpr (i > 0) {
+            NflActEpi<NP, NCB, RELU, STASH, NOUT> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1)};
+            nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
+        } else {
+            NflNoEpi epi;
+            nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
+        }
+        // pieces the k-loop of this chunk did not get to
+        if (i % TPC == TPC - 1 || i == NRT - 1) ring.template pieces<((i % TPC) + 1) * NK, Ring::MAXP>();
     });
-    nfl_store_act<NP, NCB, RELU, NOUT>(acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1));
+    NflActEpi<NP, NCB, RELU, STASH, NOUT> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1)};
+    last.all();
     rt += NRT;
 }
 
@@ -297,7 +377,12 @@ NFL_DEV void nfl_head(Ring& ring, const float* bias_lds, int& rt, int h,
                       const h8 (&in)[NIN][NCB][NP], int ks0, f16v (&acc)[NCB]) {
     const char* wl = ring.consume();
     nfl_bias_init<NP, NCB>(acc, bias_lds + rt * 32, h);
-    nfl_mma<NP, NCB, NK, NIN>(acc, in, ks0, wl, 0);
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
+        return in[ks0 + decltype(K)::value][cb][part];
+    };
+    NflNoEpi epi;
+    nfl_tile<NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    ring.template pieces<NK, Ring::MAXP>();
     rt += 1;
 }
 
@@ -351,7 +436,7 @@ struct NflRenderCfg {
     static constexpr int LDS_BYTES = LDS_RING + LDS_BIAS + LDS_REC + LDS_CHK;
 };
 
-template <int NSPLIT, int NCB, int NFX>
+template <int NSPLIT, int NCB, int NFX, bool STASH>
 __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) {
     using C = NflRenderCfg<NSPLIT, NCB, NFX>;
     constexpr int NP = C::NP, NKP = C::NKP, NSLOT = C::NSLOT;
@@ -417,9 +502,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             const float near = r1[2], far = r1[3];
             const float z = nfl_z_at(a, ray, near, far, ii);
             const float zn = ii + 1 < N ? nfl_z_at(a, ray, near, far, ii + 1) : z;
-            st[cb] = (a.d_act_stash && seg_ok)
-                         ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + lane * 16
-                         : nullptr;
+            // padded segments recompute (and re-store) the last real one: identical bytes, no branch
+            st[cb] = STASH ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + lane * 16
+                           : nullptr;
             s_ray[cb] = ray;
             s_idx[cb] = ii;
             s_ok[cb] = ok;
@@ -434,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             for (int k = 0; k < 3; ++k) nfl_turns(raw[k], th[k], tl[k]);
 #pragma unroll
             for (int ks = 0; ks < NKP; ++ks) {
-                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, P[ks][cb], st[cb] ? st[cb] + ks * 1024 : nullptr);
+                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, P[ks][cb], STASH ? st[cb] + ks * 1024 : nullptr);
                 __builtin_amdgcn_sched_barrier(0);      // bound the register pressure of the encoder
             }
         }
@@ -444,14 +529,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         // raw head outputs of sample c (lane half 0); extracted at once so the 16-register
         // accumulator tiles die immediately
         float o_sig[NCB], o_rgb[NCB][3], o_tr[NCB][5];
-        nfl_dense<NP, NCB, NKP, 0, true, 8, 2>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1));       // L1
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2));        // L2
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3));        // L3
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4));        // L4
-        nfl_dense<NP, NCB, NKP, 16, true, 8, 1>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5));      // L5 (skip)
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6));        // L6
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7));        // L7
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8));        // L8
+        nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1));       // L1
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2));        // L2
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3));        // L3
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4));        // L4
+        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5));      // L5 (skip)
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6));        // L6
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7));        // L7
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8));        // L8
         {
             f16v hacc[NCB];
             nfl_head<NP, NCB, 16>(ring, bias_lds, rt, h, Y, 0, hacc);                          // sigma
@@ -459,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             for (int cb = 0; cb < NCB; ++cb) o_sig[cb] = hacc[cb][0];
         }
         if (!a.sigma_only) {
-            nfl_dense<NP, NCB, 16, 0, false, 8, 1>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP));   // final (linear)
+            nfl_dense<NP, NCB, 16, 0, false, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP));   // final (linear)
             {
                 h8 D[5][NCB][NP];
 #pragma unroll
@@ -472,10 +557,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         raw[k] = dp[k];
                         nfl_turns(raw[k], th[k], tl[k]);
                     }
-                    char* sd = st[cb] ? st[cb] + nfl_act_d(NKP) * 1024 : nullptr;
+                    char* sd = STASH ? st[cb] + nfl_act_d(NKP) * 1024 : nullptr;
                     nfl_pe_kstep<4, NP>(0, h, raw, th, tl, D[0][cb], sd);
                     __builtin_amdgcn_sched_barrier(0);
-                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, D[1][cb], sd ? sd + 1024 : nullptr);
+                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, D[1][cb], STASH ? sd + 1024 : nullptr);
                     __builtin_amdgcn_sched_barrier(0);
                     if (A.has_a) {
                         const float* ap = a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;
@@ -485,14 +570,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                             const f4v v1 = *reinterpret_cast<const f4v*>(ap + 16 * ks + 4);
                             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                             nfl_split8<NP>(v, D[2 + ks][cb]);
-                            if (sd) nfl_stash8(v, sd + (2 + ks) * 1024);
+                            if (STASH) nfl_stash8(v, sd + (2 + ks) * 1024);
                         }
                     }
                 }
                 if (A.has_a)
-                    nfl_dense<NP, NCB, 16, 5, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
+                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
                 else
-                    nfl_dense<NP, NCB, 16, 2, true, 4, 1>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
+                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
             }
             {
                 f16v hacc[NCB];
@@ -513,12 +598,12 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     const f4v v1 = *reinterpret_cast<const f4v*>(tp + 4);
                     const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     nfl_split8<NP>(v, T[0][cb]);
-                    if (st[cb]) nfl_stash8(v, st[cb] + nfl_act_tau(NKP) * 1024);
+                    if (STASH) nfl_stash8(v, st[cb] + nfl_act_tau(NKP) * 1024);
                 }
-                nfl_dense<NP, NCB, 16, 1, true, 4, 1>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0, st, nfl_act_g(NKP, 1));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 2));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0, st, nfl_act_g(NKP, 3));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 4));
+                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0, st, nfl_act_g(NKP, 1));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 2));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0, st, nfl_act_g(NKP, 3));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 4));
                 f16v hacc[NCB];
                 nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 8, hacc);
 #pragma unroll
@@ -690,8 +775,8 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two prefetched chunks before exit
 }
 
-template <int NSPLIT, int NCB, int NFX>
-static int nfl_launch_render(const NflPlan* hp, const void* d_plan, const void* d_packed,
+template <int NSPLIT, int NCB, int NFX, bool STASH>
+static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void* d_packed,
                              const nfl_pass_args* args, hipStream_t stream) {
     using C = NflRenderCfg<NSPLIT, NCB, NFX>;
     RenderArgs A;
@@ -719,11 +804,21 @@ static int nfl_launch_render(const NflPlan* hp, const void* d_plan, const void* 
     const int grid = (args->n_rays + rpw - 1) / rpw;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_render_kernel<NSPLIT, NCB, NFX>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_render_kernel<NSPLIT, NCB, NFX, STASH>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
             return NFL_ENODEV;
         attr_set = true;
     }
-    hipLaunchKernelGGL((nfl_render_kernel<NSPLIT, NCB, NFX>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
+    hipLaunchKernelGGL((nfl_render_kernel<NSPLIT, NCB, NFX, STASH>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}
+
+template <int NSPLIT, int NCB, int NFX>
+static int nfl_launch_render(const NflPlan* hp, const void* d_plan, const void* d_packed,
+                             const nfl_pass_args* args, hipStream_t stream) {
+    if (args->d_act_stash) {
+        if (NSPLIT != 3) return NFL_EINVAL;        // the training stash is written by the accurate mode only
+        return nfl_launch_render_t<NSPLIT, NCB, NFX, (NSPLIT == 3)>(hp, d_plan, d_packed, args, stream);
+    }
+    return nfl_launch_render_t<NSPLIT, NCB, NFX, false>(hp, d_plan, d_packed, args, stream);
 }

@@ -82,7 +82,7 @@ def test_bwd_plan_structure(L):
     assert L.nfl_bwd_packed_bytes(C.byref(d)) == total_ks * 2048 + n_rt * 128
     # stash sizes: per 32-sample segment 194 / 189 KiB (+ 4 KiB tail pad)
     assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 194 * 1024 + 4096
-    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == 8 * 4 * 189 * 1024 + 4096
+    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == (8 * 4 + 1) * 189 * 1024 + 4096
 
 
 def test_unsupported_configs_rejected(L):
