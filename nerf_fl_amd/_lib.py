@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnerf_fl_amd.so")
+LIB_PATH = os.environ.get("NFL_LIB") or os.path.join(_HERE, "libnerf_fl_amd.so")
 
 NFL_ABI_VERSION = 1
 NFL_PREC_F16X3 = 0

@@ -57,13 +57,18 @@ struct NflRingAux {
     char* i_dst;
     int i_nbytes;
 
+    int n_off0, n_off1, n_aux;    // table entries of chunk c_issue, fetched one step ahead
+
+    NFL_DEV void fetch_tables() {
+        n_off0 = __builtin_amdgcn_readfirstlane(chunk_off[c_issue]);
+        n_off1 = __builtin_amdgcn_readfirstlane(chunk_off[c_issue + 1]);
+        n_aux = __builtin_amdgcn_readfirstlane(chunk_aux[c_issue]);
+    }
     NFL_DEV void begin_issue() {
-        const int off0 = chunk_off[c_issue];
-        i_nbytes = chunk_off[c_issue + 1] - off0;
-        i_src = gsrc + off0;
+        i_nbytes = n_off1 - n_off0;
+        i_src = gsrc + n_off0;
         i_dst = lds + s_issue * SLOT_BYTES;
-        int slot = chunk_aux[c_issue];
-        slot = slot < 0 ? 0 : slot;
+        const int slot = n_aux < 0 ? 0 : n_aux;
         i_aux = aux_src + (size_t)seg_issue * seg_stride + slot * 1024;
         if (c_issue + 1 == n_chunks) {
             c_issue = c_start;
@@ -72,18 +77,21 @@ struct NflRingAux {
             c_issue = c_issue + 1;
         }
         s_issue = s_issue == 2 ? 0 : s_issue + 1;
+        fetch_tables();
     }
     template <int P>
     NFL_DEV void piece() {
         if constexpr (P < MAXPW) {
-            int byte = (wave + 4 * P) * 1024;
-            byte = byte < i_nbytes ? byte : i_nbytes - 1024;
+            unsigned byte = (unsigned)(wave + 4 * P) * 1024u;
+            const unsigned last = (unsigned)i_nbytes - 1024u;
+            byte = byte < last ? byte : last;
+            const unsigned vo = byte + (threadIdx.x & 63) * 16u;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(i_src + byte + (threadIdx.x & 63) * 16),
+                (const __attribute__((address_space(1))) void*)(i_src + vo),
                 (__attribute__((address_space(3))) void*)(i_dst + byte), 16, 0, 0);
         } else if constexpr (P < MAXP) {
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(i_aux + (P - MAXPW) * 1024 + (threadIdx.x & 63) * 16),
+                (const __attribute__((address_space(1))) void*)(i_aux + (unsigned)((P - MAXPW) * 1024u + (threadIdx.x & 63) * 16u)),
                 (__attribute__((address_space(3))) void*)(i_dst + WBYTES + wave * 2048 + (P - MAXPW) * 1024), 16, 0, 0);
         }
     }
@@ -92,6 +100,7 @@ struct NflRingAux {
         nfl_static_for<P0, P1>([&](auto P) __attribute__((always_inline)) { piece<decltype(P)::value>(); });
     }
     NFL_DEV void prime() {
+        fetch_tables();
         begin_issue();
         pieces<0, MAXP>();
         begin_issue();
@@ -144,9 +153,13 @@ struct DgEpi {
     }
     template <int K, int NK>
     NFL_DEV void step() {
-        nfl_static_for<(8 * K) / NK, (8 * (K + 1)) / NK>([&](auto O) __attribute__((always_inline)) {
+        constexpr int R = 8 - NFL_EPI_EARLY;
+        nfl_static_for<NFL_EPI_EARLY + (R * K) / NK, NFL_EPI_EARLY + (R * (K + 1)) / NK>([&](auto O) __attribute__((always_inline)) {
             pair<decltype(O)::value>();
         });
+    }
+    NFL_DEV void early() {
+        nfl_static_for<0, NFL_EPI_EARLY>([&](auto O) __attribute__((always_inline)) { pair<decltype(O)::value>(); });
     }
     NFL_DEV void all() {
         nfl_static_for<0, 8>([&](auto O) __attribute__((always_inline)) { pair<decltype(O)::value>(); });

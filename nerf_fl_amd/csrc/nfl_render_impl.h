@@ -183,21 +183,27 @@ struct NflRing {
     char* i_dst;
     int i_nbytes;
 
+    int n_off0, n_off1;   // table entries of chunk c_issue, fetched one step ahead (no LDS latency after the barrier)
+
     NFL_DEV void begin_issue() {
-        const int off0 = chunk_off[c_issue];
-        i_nbytes = chunk_off[c_issue + 1] - off0;
-        i_src = gsrc + off0;                 // wave-uniform; the lane offset is added per piece (keeps no 64-bit VGPR live)
+        i_nbytes = n_off1 - n_off0;
+        i_src = gsrc + n_off0;               // wave-uniform; the lane offset is added per piece (keeps no 64-bit VGPR live)
         i_dst = lds + s_issue * SLOT_BYTES;
         c_issue = c_issue + 1 == n_chunks ? 0 : c_issue + 1;
         s_issue = s_issue == 2 ? 0 : s_issue + 1;
+        n_off0 = __builtin_amdgcn_readfirstlane(chunk_off[c_issue]);
+        n_off1 = __builtin_amdgcn_readfirstlane(chunk_off[c_issue + 1]);
     }
     template <int P>
     NFL_DEV void piece() {
         if constexpr (P < MAXP) {
-            int byte = (wave + 4 * P) * 1024;
-            byte = byte < i_nbytes ? byte : i_nbytes - 1024;       // surplus pieces re-copy the last KiB
+            // uniform byte offset (SALU min), one VALU add for the lane: SGPR base + 32-bit VGPR offset
+            unsigned byte = (unsigned)(wave + 4 * P) * 1024u;
+            const unsigned last = (unsigned)i_nbytes - 1024u;
+            byte = byte < last ? byte : last;                      // surplus pieces re-copy the last KiB
+            const unsigned vo = byte + (threadIdx.x & 63) * 16u;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(i_src + byte + (threadIdx.x & 63) * 16),
+                (const __attribute__((address_space(1))) void*)(i_src + vo),
                 (__attribute__((address_space(3))) void*)(i_dst + byte), 16, 0, 0);
         }
     }
@@ -206,6 +212,8 @@ struct NflRing {
         nfl_static_for<P0, P1>([&](auto P) __attribute__((always_inline)) { piece<decltype(P)::value>(); });
     }
     NFL_DEV void prime() {
+        n_off0 = __builtin_amdgcn_readfirstlane(chunk_off[c_issue]);
+        n_off1 = __builtin_amdgcn_readfirstlane(chunk_off[c_issue + 1]);
         begin_issue();
         pieces<0, MAXP>();
         begin_issue();
@@ -263,6 +271,8 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
     };
     load(std::integral_constant<int, 0>{});
     if constexpr (NK > 1) load(std::integral_constant<int, 1>{});
+    epi.early();                         // VALU work that hides the latency of the first LDS reads
+    __builtin_amdgcn_sched_barrier(0);
     nfl_static_for<0, NK>([&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
 #pragma unroll
@@ -290,7 +300,9 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
 
 struct NflNoEpi {
     template <int K, int NK> NFL_DEV void step() {}
+    NFL_DEV void early() {}
 };
+#define NFL_EPI_EARLY 2      // pair-ops done before the first MFMA of the following tile
 
 // Epilogue of an accumulator tile -> the two k-steps (ks, ks+1) of the next layer's B operand
 // (and, in the training forward, the bf16 activation stash), cut into 8 pair-ops per column
@@ -310,7 +322,10 @@ struct NflActEpi {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
-            if (RELU) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+            if (RELU) {      // v_med3_f32: one instruction, no canonicalising v_max in front
+                x0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff());
+                x1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
+            }
             const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
             out[ks + s][cb][0][j] = h0;
             out[ks + s][cb][0][j + 1] = h1;
@@ -326,10 +341,14 @@ struct NflActEpi {
         }
     }
     template <int K, int NK>
-    NFL_DEV void step() {                      // pair-ops [8K/NK, 8(K+1)/NK)
-        nfl_static_for<(8 * K) / NK, (8 * (K + 1)) / NK>([&](auto O) __attribute__((always_inline)) {
+    NFL_DEV void step() {                      // the remaining pair-ops, spread evenly over the k-steps
+        constexpr int R = 8 - NFL_EPI_EARLY;
+        nfl_static_for<NFL_EPI_EARLY + (R * K) / NK, NFL_EPI_EARLY + (R * (K + 1)) / NK>([&](auto O) __attribute__((always_inline)) {
             pair<decltype(O)::value>();
         });
+    }
+    NFL_DEV void early() {
+        nfl_static_for<0, NFL_EPI_EARLY>([&](auto O) __attribute__((always_inline)) { pair<decltype(O)::value>(); });
     }
     NFL_DEV void all() {
         nfl_static_for<0, 8>([&](auto O) __attribute__((always_inline)) { pair<decltype(O)::value>(); });
