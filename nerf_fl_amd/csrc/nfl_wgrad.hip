@@ -68,11 +68,17 @@ __device__ __forceinline__ int wg_orig(int kind, int i) {
     return kind == NFL_SEG_ACT ? 16 * (i >> 4) + 8 * ((i & 7) >> 2) + 4 * ((i >> 3) & 1) + (i & 3) : i;
 }
 
-// feature-on-lane MFMA operand of MFMA k-step m (samples 16m..16m+15) from a 2 KiB tile image
+#define WG_PSTRIDE 1056   // LDS stride of a 1 KiB k-step image: +32 B so the two k-steps of a tile fall on
+                          // different banks for the transposed reads (4-way -> 2-way conflicts)
+#define WG_TSTRIDE (2 * WG_PSTRIDE)
+#undef WG_SLOT
+#define WG_SLOT (WG_TSTRIDE * (WG_MAX_OT + WG_MAX_IT))
+
+// feature-on-lane MFMA operand of MFMA k-step m (samples 16m..16m+15) from a tile image (2 k-step pieces)
 __device__ __forceinline__ b8 wg_operand(const char* tile, int lane, int m) {
     const int g = lane >> 4, ip = lane & 15, q = ip >> 2, p = ip & 3;
     const int c = 16 * m + 8 * (g >> 1) + q;
-    const char* ad = tile + (g & 1) * 1024 + (((p >> 1) * 32 + c) * 8 + 4 * (p & 1)) * 2;
+    const char* ad = tile + (g & 1) * WG_PSTRIDE + (((p >> 1) * 32 + c) * 8 + 4 * (p & 1)) * 2;
     const b4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad));
     const b4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad + 4 * 8 * 2));
     b8 r;
@@ -89,7 +95,9 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
     }
 }
 
-template <int PW>
+// PW: DMA pieces per wave per segment; NITW: in tiles per wave.  No branch inside the segment loop:
+// a wave whose share is short works on a clamped (duplicate) tile and drops it at the flush.
+template <int PW, int NITW>
 __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const int act_slots, const int grd_slots,
                                         const int seg0, const int seg1, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -97,7 +105,6 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
     const int wo = wave % J.n_wo, wi = wave / J.n_wo;
     const int n_pieces = 2 * (J.n_ot + J.n_it);
 
-    // this wave's DMA pieces: source base (+ lane*16), per-segment stride, LDS offset
     const char* psrc[PW];
     size_t pstride[PW];
     int pdst[PW];
@@ -110,7 +117,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
         const int slot = (is_out ? J.ot[t].slot : J.it[t - J.n_ot].slot) + (p & 1);
         psrc[pp] = (is_out ? A.grd : A.act) + (size_t)slot * 1024 + lane * 16;
         pstride[pp] = (size_t)(is_out ? grd_slots : act_slots) * 1024;
-        pdst[pp] = p * 1024;
+        pdst[pp] = p * WG_PSTRIDE;
     }
     auto issue = [&](int seg, int s) __attribute__((always_inline)) {
         const int sg = seg < seg1 ? seg : seg1 - 1;          // surplus issues re-read the last segment
@@ -121,55 +128,54 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
                 (__attribute__((address_space(3))) void*)(smem + s * WG_SLOT + pdst[pp]), 16, 0, 0);
     };
 
-    f16v acc[WG_NOT][WG_MAX_IT];
+    // tiles of this wave (clamped into range; duplicates are dropped at the flush)
+    int my_ot[WG_NOT], my_it[NITW];
+#pragma unroll
+    for (int a = 0; a < WG_NOT; ++a) my_ot[a] = wo * WG_NOT + a < J.n_ot ? wo * WG_NOT + a : J.n_ot - 1;
+#pragma unroll
+    for (int b = 0; b < NITW; ++b) my_it[b] = wi + b * J.n_wi < J.n_it ? wi + b * J.n_wi : J.n_it - 1;
+
+    f16v acc[WG_NOT][NITW];
 #pragma unroll
     for (int a = 0; a < WG_NOT; ++a)
 #pragma unroll
-        for (int b = 0; b < WG_MAX_IT; ++b)
+        for (int b = 0; b < NITW; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float bsum[WG_NOT] = {0.f, 0.f};
-    // in tiles of this wave: wi, wi + n_wi, ...
-    const int n_my_it = (J.n_it - wi + J.n_wi - 1) / J.n_wi;
 
+    // 4-slot ring, three segments in flight
     issue(seg0, 0);
     issue(seg0 + 1, 1);
-    int s_read = 0, s_issue = 2;
+    issue(seg0 + 2, 2);
+    int s_read = 0, s_issue = 3;
     for (int seg = seg0; seg < seg1; ++seg) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(seg + 2, s_issue);
-        s_issue = s_issue == 2 ? 0 : s_issue + 1;
+        issue(seg + 3, s_issue);
+        s_issue = (s_issue + 1) & 3;
         const char* base = smem + s_read * WG_SLOT;
-        s_read = s_read == 2 ? 0 : s_read + 1;
+        s_read = (s_read + 1) & 3;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            b8 av[WG_NOT];
+            b8 av[WG_NOT], bv[NITW];
+#pragma unroll
+            for (int a = 0; a < WG_NOT; ++a) av[a] = wg_operand(base + my_ot[a] * WG_TSTRIDE, lane, m);
+#pragma unroll
+            for (int b = 0; b < NITW; ++b) bv[b] = wg_operand(base + (J.n_ot + my_it[b]) * WG_TSTRIDE, lane, m);
 #pragma unroll
             for (int a = 0; a < WG_NOT; ++a) {
-                const int ot = wo * WG_NOT + a;
-                if (ot < J.n_ot) {
-                    av[a] = wg_operand(base + ot * 2048, lane, m);
-                    if (J.do_bias && wi == 0) {
-                        float s = 0.f;
+                float s = 0.f;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) s += (float)av[a][j];
-                        bsum[a] += s;
-                    }
-                }
+                for (int j = 0; j < 8; ++j) s += (float)av[a][j];
+                bsum[a] += s;
             }
-            wg_static_for<0, WG_MAX_IT>([&](auto B) __attribute__((always_inline)) {
-                constexpr int b = decltype(B)::value;
-                if (b < n_my_it) {
-                    const int it = wi + b * J.n_wi;
-                    const b8 bv = wg_operand(base + (J.n_ot + it) * 2048, lane, m);
 #pragma unroll
-                    for (int a = 0; a < WG_NOT; ++a)
-                        if (wo * WG_NOT + a < J.n_ot)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv, acc[a][b], 0, 0, 0);
-                }
-            });
+            for (int b = 0; b < NITW; ++b)
+#pragma unroll
+                for (int a = 0; a < WG_NOT; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -183,9 +189,9 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
         const WgTile TO = J.ot[ot];
         const int layer = J.bias_layer_of_ot[ot] >= 0 ? J.bias_layer_of_ot[ot] : J.layer;
         float* W = A.g.weight[layer];
-        wg_static_for<0, WG_MAX_IT>([&](auto B) __attribute__((always_inline)) {
+        wg_static_for<0, NITW>([&](auto B) __attribute__((always_inline)) {
             constexpr int b = decltype(B)::value;
-            if (b < n_my_it && W != nullptr) {
+            if (wi + b * J.n_wi < J.n_it && W != nullptr) {
                 const WgTile TI = J.it[wi + b * J.n_wi];
                 const int on = wg_orig(TI.kind, n);
                 if (on < TI.nvalid) {
@@ -216,9 +222,17 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     if (seg0 >= seg1) return;
     const WgJob& J = P.job[j];
     const int pw = P.cost[j];
-    if (pw <= 4) wg_body<4>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-    else if (pw <= 5) wg_body<5>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-    else wg_body<8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+    const int nitw = (J.n_it + J.n_wi - 1) / J.n_wi;       // in tiles per wave
+    if (pw <= 4) {
+        if (nitw <= 1) wg_body<4, 1>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        else wg_body<4, 2>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+    } else if (pw <= 5) {
+        wg_body<5, 2>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+    } else {
+        if (nitw <= 5) wg_body<8, 5>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        else if (nitw <= 6) wg_body<8, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        else wg_body<8, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -374,10 +388,10 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 3 * WG_SLOT) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_SLOT) != hipSuccess)
             return NFL_ENODEV;
         attr_set = true;
     }
-    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 3 * WG_SLOT, static_cast<hipStream_t>(stream), A);
+    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 4 * WG_SLOT, static_cast<hipStream_t>(stream), A);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }
