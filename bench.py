@@ -51,8 +51,10 @@ def build_models(dev):
 
 
 def cpu_baseline(n_rays=4096, reps=3):
-    """The oracle (CPU restatement of the reference, eager PyTorch fp32) on the host cores."""
+    """The oracle (CPU restatement of the reference, eager PyTorch fp32) on the host cores.
+    A 1-GPU box gives this job a 16-CPU share; more threads than that only oversubscribe."""
     from oracle import nerfw_oracle as orc
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     torch.manual_seed(0)
     spec_c, spec_f = orc.FieldSpec("coarse"), orc.FieldSpec("fine")
     P_c, P_f = orc.make_field_params(spec_c, 11, "sharp"), orc.make_field_params(spec_f, 12, "sharp")
@@ -201,8 +203,19 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12
         from nerf_fl_amd import _lib
         kname = _lib.lib().nfl_render_kernel_name(rnd._PREC[args.precision], 10).decode()
+        # HBM bytes per launch of this kernel from the committed PMC profile (FETCH_SIZE doubled as the
+        # gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); collected by rocprofv3 --pmc in
+        # separate passes, so it cannot be measured inside this process
+        traffic = None
+        try:
+            summ = json.load(open(os.path.join(ROOT, "profiles", "r01_summary.json")))
+            for k, v in summ["traffic"].items():
+                if kname.split("(")[0] in k:
+                    traffic = v["hbm_bytes_max_launch"]
+        except Exception:
+            pass
         out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": None,
+                           "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": traffic,
                            "kernel": kname, "launch_ms": ms,
                            "note": "algorithmic FLOPs (2 x 593408 MAC per field evaluation x 4096 rays x 128 samples); "
                                    "f16x3 issues 3 MFMA products per algorithmic product"}
