@@ -1,0 +1,86 @@
+"""Chunked no-grad inference for whole images / video frames (reference eval.py:80-110).
+
+`batched_inference` mirrors the reference helper of the same name: it walks the rays in
+chunks of `chunk` rays, calls render_rays(..., test_time=True) on each and concatenates the
+per-key results.  Differences that matter on MI355X:
+
+  * results stay on the GPU (the reference moves every chunk to the host, eval.py:106);
+  * every chunk has the same shape -- the last, ragged one is padded with copies of its final
+    ray and the padding is dropped on write-back -- so one chunk can be captured ONCE into a
+    HIP graph (`use_graph=True`) and replayed: a frame becomes a handful of graph launches
+    with no per-kernel host work (config 5: 128+128 samples, chunk 131072).
+"""
+import torch
+
+from .rendering import render_rays
+
+__all__ = ["batched_inference", "GraphedChunk"]
+
+
+class GraphedChunk:
+    """One fixed-shape render_rays(test_time=True) call captured in a HIP graph."""
+
+    def __init__(self, models, embeddings, chunk, device, N_samples, use_disp, N_importance, white_back, **kwargs):
+        self.chunk = chunk
+        self.rays = torch.zeros(chunk, 8, device=device)
+        self.rays[:, 3:6] = torch.tensor([0.0, 0.0, -1.0], device=device)
+        self.rays[:, 6], self.rays[:, 7] = 2.0, 6.0
+        self.ts = torch.zeros(chunk, dtype=torch.long, device=device)
+        self.kw_static = {}
+        for k in ("a_embedded", "t_embedded"):       # per-frame latent overrides (test_phototourism.ipynb cell 11)
+            if kwargs.get(k) is not None:
+                self.kw_static[k] = kwargs[k].expand(chunk, -1).contiguous().clone()
+        other = {k: v for k, v in kwargs.items() if k not in self.kw_static}
+
+        def run():
+            return render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, 0, 0, N_importance,
+                               chunk, white_back, True, **self.kw_static, **other)
+
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), torch.no_grad():      # warm-up: packs weights, sets kernel attributes
+            run()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.out = run()
+
+    def __call__(self, rays, ts, **latents):
+        n = rays.shape[0]
+        self.rays[:n].copy_(rays)
+        self.ts[:n].copy_(ts)
+        if n < self.chunk:                                   # ragged tail: repeat the last ray
+            self.rays[n:].copy_(rays[-1:].expand(self.chunk - n, -1))
+            self.ts[n:].copy_(ts[-1:].expand(self.chunk - n))
+        for k, buf in self.kw_static.items():
+            if k in latents:
+                buf.copy_(latents[k].expand(self.chunk, -1))
+        self.graph.replay()
+        return {k: v[:n] for k, v in self.out.items()}
+
+
+@torch.no_grad()
+def batched_inference(models, embeddings, rays, ts, N_samples, N_importance, use_disp=False, chunk=1024 * 128,
+                      white_back=False, use_graph=False, _graph_cache=None, **kwargs):
+    """Same arguments as the reference's eval.batched_inference (eval.py:80-88) plus `use_graph`.
+    Returns a dict of GPU tensors covering all `rays`."""
+    B = rays.shape[0]
+    results = {}
+    runner = None
+    if use_graph:
+        key = (chunk, N_samples, N_importance, bool(use_disp), bool(white_back), str(rays.device))
+        cache = _graph_cache if _graph_cache is not None else {}
+        if key not in cache:
+            cache[key] = GraphedChunk(models, embeddings, chunk, rays.device, N_samples, use_disp, N_importance,
+                                      white_back, **kwargs)
+        runner = cache[key]
+    for i in range(0, B, chunk):
+        r, t = rays[i:i + chunk], ts[i:i + chunk]
+        if runner is not None:
+            out = {k: v.clone() for k, v in runner(r, t).items()}
+        else:
+            out = render_rays(models, embeddings, r, t, N_samples, use_disp, 0, 0, N_importance, chunk, white_back,
+                              True, **kwargs)
+        for k, v in out.items():
+            results.setdefault(k, []).append(v)
+    return {k: torch.cat(v, 0) for k, v in results.items()}
