@@ -93,7 +93,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("NFL_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on one GPU
+        if os.environ.get("NFL_BENCH_ONE_DEVICE"):
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

@@ -106,8 +106,9 @@ struct NflRingAux {
         begin_issue();
         pieces<0, MAXP>();
     }
+    template <int EXTRA = 0>
     NFL_DEV const char* consume() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + EXTRA) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         begin_issue();
@@ -183,7 +184,7 @@ NFL_DEV void dg_tiles(Ring& ring, int wave,
     };
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        const char* wl = ring.consume();
+        const char* wl = ring.template consume<(i >= 2) ? 2 : 0>();   // tile i-1 carried tile i-2's two stash stores
         dg_zero(acc[i & 1]);
         if (MASK) {      // the slot is recycled at the next consume(): take the mask now
             mk[i & 1][0] = *reinterpret_cast<const b8*>(wl + WB + wave * 2048);

@@ -222,9 +222,12 @@ struct NflRing {
     // Wait for the oldest chunk in flight, make it visible to all waves and return this lane's
     // read base; the caller then issues the MAXP pieces of the next chunk (piece<P>()) while it
     // computes, into the slot everybody has just finished reading.
+    // EXTRA: VMEM ops (stash stores) known to have been issued after the pieces of the chunk waited for,
+    // besides the MAXP pieces of the next one -- without it the wait would also sit on those stores.
+    template <int EXTRA = 0>
     NFL_DEV const char* consume() {
-        // all but the MAXP youngest VMEM ops (= the younger chunk's pieces) are done
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP) : "memory");
+        // all but the MAXP (+EXTRA) youngest VMEM ops (= the younger chunk's pieces) are done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + EXTRA) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         begin_issue();
@@ -372,7 +375,8 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
     };
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        if (i % TPC == 0) wl = ring.consume();
+        // tile i-1 carried the stash stores of tile i-2's epilogue, issued after this chunk's pieces
+        if (i % TPC == 0) wl = ring.template consume<(STASH && TPC == 1 && i >= 2) ? 2 * NCB : 0>();
         constexpr int frag0 = (i % TPC) * NK;
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         if constexpr (i > 0) {
