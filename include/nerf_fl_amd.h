@@ -140,6 +140,10 @@ typedef struct nfl_pass_args {
                                    required (with d_act_stash) when a backward will follow                      */
     char*  d_act_stash;         /* nfl_act_stash_bytes(): bf16 layer inputs of every sample, MFMA fragment order,
                                    consumed by nfl_render_backward; NULL for inference                          */
+    /* BARF coarse-to-fine encoding (reference BarfPosEmbedding, nerf.py:35-77): per-frequency weights,
+       computed by the caller exactly as barf_weight(freq, epoch) does; NULL = plain PosEmbedding     */
+    const float* d_pe_w_xyz;    /* (n_emb_xyz) or NULL                                                   */
+    const float* d_pe_w_dir;    /* (n_emb_dir) or NULL                                                   */
 } nfl_pass_args;
 
 /* Evaluate the field on every sample of every ray and alpha-composite on the
@@ -158,8 +162,10 @@ size_t nfl_act_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n
 size_t nfl_grad_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples);
 /* dgrad plan / packed stream (transposed weights, bf16 hi+lo); same calling pattern as
  * nfl_plan_build / nfl_pack_field (pack with nfl_pack_field using these plans). */
-int    nfl_bwd_plan_build(const nfl_field_desc* desc, void* h_plan, size_t bytes);
-size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc);
+/* rays_grad != 0: the stream also carries the tiles needed for the gradient w.r.t. the rays
+ * (learnable poses, reference models/poses.py + train.py:86-98). */
+int    nfl_bwd_plan_build(const nfl_field_desc* desc, int32_t rays_grad, void* h_plan, size_t bytes);
+size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc, int32_t rays_grad);
 
 typedef struct nfl_compbwd_args {
     const float* d_field_raw;       /* (R*N,9) from the forward pass                       */
@@ -192,6 +198,12 @@ typedef struct nfl_dgrad_args {
     int32_t reserved;
     float* d_g_a_emb;               /* (R,n_a)  accumulated into (zero it first) or NULL   */
     float* d_g_t_emb;               /* (R,n_tau) accumulated into (zero it first) or NULL  */
+    /* gradient w.r.t. the rays (needs a plan built with rays_grad = 1) */
+    float* d_g_rays;                /* (R,8) accumulated into: columns 0..2 origin, 3..5 direction; 6,7 untouched; or NULL */
+    const float* d_rays;            /* (R,8) as given to the forward pass                  */
+    const float* d_z;               /* (R,N) depths the forward pass used                  */
+    const float* d_pe_w_xyz;        /* as given to the forward pass (NULL = ones)          */
+    const float* d_pe_w_dir;
 } nfl_dgrad_args;
 int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
                   const nfl_dgrad_args* args, void* stream);

@@ -54,6 +54,7 @@ class PassArgs(C.Structure):
         ("d_rgb_static_only", C.c_void_p), ("d_depth_static_only", C.c_void_p),
         ("d_rgb_transient_only", C.c_void_p), ("d_depth_transient_only", C.c_void_p),
         ("d_field_raw", C.c_void_p), ("d_act_stash", C.c_void_p),
+        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p),
     ]
 
 
@@ -73,6 +74,8 @@ class DgradArgs(C.Structure):
         ("d_head_grads", C.c_void_p), ("d_act_stash", C.c_void_p), ("d_grad_stash", C.c_void_p),
         ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("use_transient", C.c_int32), ("reserved", C.c_int32),
         ("d_g_a_emb", C.c_void_p), ("d_g_t_emb", C.c_void_p),
+        ("d_g_rays", C.c_void_p), ("d_rays", C.c_void_p), ("d_z", C.c_void_p),
+        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p),
     ]
 
 
@@ -92,8 +95,8 @@ SYMBOLS = [
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nfl_act_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
     ("nfl_grad_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
-    ("nfl_bwd_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_void_p, C.c_size_t]),
-    ("nfl_bwd_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc)]),
+    ("nfl_bwd_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),
+    ("nfl_bwd_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32]),
     ("nfl_composite_backward", C.c_int, [C.POINTER(CompBwdArgs), C.c_void_p]),
     ("nfl_mlp_dgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DgradArgs), C.c_void_p]),
     ("nfl_wgrad_plan_bytes", C.c_size_t, []),

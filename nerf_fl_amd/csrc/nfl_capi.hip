@@ -46,14 +46,14 @@ size_t nfl_grad_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_s
     if (!d || n_rays < 0 || n_samples < 1) return 0;
     return (n_segments(n_rays, n_samples) + 1) * NFL_GRD_SLOTS * 1024 + 4096;   // + one scratch record for padded segments
 }
-int nfl_bwd_plan_build(const nfl_field_desc* desc, void* h_plan, size_t bytes) {
+int nfl_bwd_plan_build(const nfl_field_desc* desc, int32_t rays_grad, void* h_plan, size_t bytes) {
     if (!h_plan) return NFL_EINVAL;
     if (bytes < sizeof(NflPlan)) return NFL_ESMALL;
-    return nfl_plan_fill_bwd(desc, static_cast<NflPlan*>(h_plan));
+    return nfl_plan_fill_bwd(desc, rays_grad, static_cast<NflPlan*>(h_plan));
 }
-size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc) {
+size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc, int32_t rays_grad) {
     NflPlan p;
-    if (nfl_plan_fill_bwd(desc, &p) != NFL_OK) return 0;
+    if (nfl_plan_fill_bwd(desc, rays_grad, &p) != NFL_OK) return 0;
     return (size_t)p.packed_bytes;
 }
 

@@ -22,6 +22,7 @@ struct DgradArgs {
     int n_chunks, c_start;
     int has_a, has_t, use_t;
     int spr, rays_per_wg, nkp, n_seg_total;
+    int rays_tiles;           // the stream carries the encoded-position / direction rows (gradient w.r.t. rays)
 };
 
 template <int NFX>
@@ -34,7 +35,7 @@ struct NflDgradCfg {
     static constexpr int AUXB = 4 * 2048;
     static constexpr int SLOT = WBYTES + AUXB;
     static constexpr int MAXP = (WBYTES + 4095) / 4096;
-    static constexpr int LDS_TAB = 2 * (NFL_MAX_CHUNKS + 8) * 4;
+    static constexpr int LDS_TAB = (2 * (NFL_MAX_CHUNKS + 8) + 32) * 4;
     static constexpr int LDS_BYTES = LDS_TAB + 3 * SLOT;
 };
 
@@ -223,6 +224,51 @@ NFL_DEV void dg_latent_tile(Ring& ring, const b8 (&in)[NIN][1][2], int ks0, floa
     }
 }
 
+// A transposed tile whose rows are positional-encoding features (tile T covers features 32T..32T+31 of
+// an N-frequency encoding): chain the feature gradients through d/dx [x, w_k sin(2^k x), w_k cos(2^k x)]
+// into the gradient of the 3 encoded coordinates of this lane's sample (partial: the two lane halves
+// hold different rows and are summed by the caller).
+template <int N, int T, int NK, int NIN, class Ring>
+NFL_DEV void dg_pe_tile(Ring& ring, const b8 (&in)[NIN][1][2], int ks0, int h,
+                        const float (&raw)[3], const float (&th)[3], const float (&tl)[3], const float* pw,
+                        float (&g)[3]) {
+    const char* wl = ring.consume();
+    f16v acc[1];
+    dg_zero(acc);
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const b8& {
+        return in[ks0 + decltype(K)::value][0][part];
+    };
+    NflNoEpi epi;
+    nfl_tile<2, 1, NK, 0, b8>(acc, wl, 0, getb, epi, ring);
+    ring.template pieces<NK, Ring::MAXP>();
+    (void)raw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int f0 = 32 * T + (r & 3) + 8 * (r >> 2), f1 = f0 + 4;      // rows of lane half 0 / 1
+        constexpr int NF = 6 * N + 3;
+        if (f0 >= NF) continue;
+        // descriptor of a feature: coordinate, scale 2^k, phase of the DERIVATIVE in turns, weight index (-1: raw x)
+        const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3, c1 = f1 < 3 ? f1 : (f1 - 3) % 3;
+        const int k0 = f0 < 3 ? -1 : (f0 - 3) / 6, k1 = f1 < 3 ? -1 : (f1 - 3) / 6;
+        const int t0 = f0 < 3 ? 0 : ((f0 - 3) % 6) / 3, t1 = f1 < 3 ? 0 : ((f1 - 3) % 6) / 3;
+        const bool v1 = f1 < NF;
+        float coef0 = 1.f, coef1 = v1 ? 1.f : 0.f;
+        if (k0 >= 0) {
+            const float sc = (float)(1 << k0);
+            const float rr = __builtin_amdgcn_fractf(th[c0] * sc) + tl[c0] * sc + (t0 ? 0.5f : 0.25f);
+            coef0 = pw[k0] * sc * nfl_sin_rev(rr);                // d sin = cos ; d cos = -sin
+        }
+        if (v1 && k1 >= 0) {
+            const float sc = (float)(1 << k1);
+            const float rr = __builtin_amdgcn_fractf(th[c1] * sc) + tl[c1] * sc + (t1 ? 0.5f : 0.25f);
+            coef1 = pw[k1] * sc * nfl_sin_rev(rr);
+        }
+        const float a = acc[0][r];
+        g[c0] += h ? 0.f : a * coef0;
+        if (v1) g[c1] += h ? a * coef1 : 0.f;
+    }
+}
+
 template <int NFX>
 __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     using C = NflDgradCfg<NFX>;
@@ -243,10 +289,13 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     const int seg_end = (ray1 - ray0) * SPR;
     const int ntiles = (seg_end + 3) / 4;
 
+    float* const pw_lds = reinterpret_cast<float*>(aux_lds + NFL_MAX_CHUNKS + 8);
     for (int i = tid; i <= A.n_chunks; i += 256) {
         chk_lds[i] = A.plan->chunk_off[i];
         aux_lds[i] = A.plan->chunk_aux[i];
     }
+    if (tid < 16) pw_lds[tid] = (a.d_pe_w_xyz && tid < NFX) ? a.d_pe_w_xyz[tid] : 1.f;
+    else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid < 20) ? a.d_pe_w_dir[tid - 16] : 1.f;
     __syncthreads();
 
     NflRingAux<C::SLOT, C::WBYTES, C::MAXP> ring;
@@ -277,6 +326,21 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         // padded segments (zero gradients) write to a scratch record past the end: no branch in the epilogue
         char* gst = a.d_grad_stash + (size_t)(seg_ok ? ray0 * SPR + gg : A.n_seg_total) * NFL_GRD_SLOTS * 1024 + lane * 16;
 
+        // geometry of this lane's sample, only for the gradient w.r.t. the rays
+        float xraw[3] = {0.f, 0.f, 0.f}, xth[3] = {0.f, 0.f, 0.f}, xtl[3] = {0.f, 0.f, 0.f};
+        float draw[3] = {0.f, 0.f, 0.f}, dth[3] = {0.f, 0.f, 0.f}, dtl[3] = {0.f, 0.f, 0.f};
+        float zs = 0.f, gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+        if (A.rays_tiles && a.d_g_rays) {
+            const float* rp = a.d_rays + (size_t)ray * 8;
+            zs = a.d_z[(size_t)ray * N + (i < N ? i : N - 1)];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                draw[k] = rp[3 + k];
+                xraw[k] = rp[k] + draw[k] * zs;
+                nfl_turns(xraw[k], xth[k], xtl[k]);
+                nfl_turns(draw[k], dth[k], dtl[k]);
+            }
+        }
         float hg[9];
         {
             const float* hp = a.d_head_grads + ((size_t)ray * N + (i < N ? i : N - 1)) * 9;
@@ -318,6 +382,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             dg_latent_tile<8>(ring, X, 0, ga, 32, h, c);
             dg_latent_tile<8>(ring, X, 0, ga ? ga + 32 : nullptr, 16, h, c);
         }
+        if (A.rays_tiles) dg_pe_tile<4, 0, 8>(ring, X, 0, h, draw, dth, dtl, pw_lds + 16, gd);
         if (A.use_t)
             dg_tiles<WB, false, 8, 8, 8, 0>(ring, wave, X, 0, Y, 8, Y, 0, Z, 0, gst, NFL_GRD_FEAT);
         else
@@ -327,9 +392,33 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(6));
         dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(5));
         dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(4));
+        if (A.rays_tiles) {       // skip connection: delta_5 (still in X) reaches the encoded position too
+            dg_pe_tile<NFX, 0, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+        }
         dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(3));
         dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(2));
         dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(1));
+        if (A.rays_tiles) {
+            dg_pe_tile<NFX, 0, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+            if (a.d_g_rays) {
+                // x = o + d z ; the view direction is d itself (no caller passes view_dir with learnable poses)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float gxk = gx[k] + __shfl_xor(gx[k], 32);
+                    const float gdk = gd[k] + __shfl_xor(gd[k], 32);
+                    const float so = nfl_sum32(gxk);
+                    const float sd = nfl_sum32(gxk * zs + gdk);
+                    if (lane == 0 && seg_ok) {
+                        atomicAdd(a.d_g_rays + (size_t)ray * 8 + k, so);
+                        atomicAdd(a.d_g_rays + (size_t)ray * 8 + 3 + k, sd);
+                    }
+                }
+            }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -347,9 +436,11 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     A.use_t = (hp->has_t && args->use_transient) ? 1 : 0;
     A.n_chunks = hp->n_chunks;
     A.c_start = (hp->has_t && !A.use_t) ? 17 : 0;
+    if (args->d_g_rays && (!A.rays_tiles || !args->d_rays || !args->d_z)) return NFL_EINVAL;
     A.spr = (args->n_samples + 31) / 32;
     A.nkp = hp->nkp;
     A.n_seg_total = args->n_rays * A.spr;
+    A.rays_tiles = hp->reserved_flags & 1;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int rpw = (args->n_rays + ncu - 1) / ncu;

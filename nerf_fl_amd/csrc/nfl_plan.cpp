@@ -112,7 +112,7 @@ static int check_desc(const nfl_field_desc* d) {
 // The dgrad stream (bf16, hi+lo): one transposed row tile per chunk, in the order the
 // backward kernel walks the network (heads first).  chunk_aux names the activation-stash
 // slot whose sign is the relu mask of that tile.
-extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, NflPlan* p) {
+extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
     common_init(d, NFL_PREC_F16X3, p);
     p->elem = 1;
@@ -140,6 +140,8 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, NflPlan* p) {
         for (int t = 0; t < 2; ++t)
             b.ttile(W + cd + 32 * t, t == 0 ? 32 : p->n_a - 32, -1,
                     [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR); });
+    if (rays_grad)      // rows of W_dir^T that multiply the encoded view direction
+        b.ttile(W, cd, -1, [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR); });
     for (int t = 0; t < 8; ++t)
         b.ttile(32 * t, 32, -1, [&](NflRowTile& r) {
             Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR);
@@ -150,10 +152,21 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, NflPlan* p) {
             Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_FINAL);
             Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_SIGMA);
         });
-    for (int l = 8; l >= 2; --l)            // layer l (1-based) transposed -> gradient of h_{l-1}
+    const int npe = (cx + 31) / 32;         // 32-row tiles covering the encoded position
+    for (int l = 8; l >= 2; --l) {          // layer l (1-based) transposed -> gradient of h_{l-1}
         for (int t = 0; t < 8; ++t)
             b.ttile((l == 5 ? cx : 0) + 32 * t, 32, nfl_act_h(nkp, l - 1) + 2 * t,
                     [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); });
+        if (l == 5 && rays_grad)            // skip connection: rows that multiply the encoded position
+            for (int t = 0; t < npe; ++t)
+                b.ttile(32 * t, cx - 32 * t < 32 ? cx - 32 * t : 32, -1,
+                        [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + 4); });
+    }
+    if (rays_grad)                          // layer 1 transposed -> gradient of the encoded position
+        for (int t = 0; t < npe; ++t)
+            b.ttile(32 * t, cx - 32 * t < 32 ? cx - 32 * t : 32, -1,
+                    [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1); });
+    p->reserved_flags = rays_grad ? 1 : 0;
     p->n_rt_sigma = p->n_rt_static = p->n_rt;
     p->n_chunks_sigma = p->n_chunks_static = p->n_chunks;
     p->total_ks = b.ks_cursor;

@@ -62,6 +62,7 @@ struct NflPlan {
     int32_t prec, nsplit;         // nsplit = 1 or 3 products; frags carry (nsplit==3 ? hi+lo : hi)
     int32_t elem;                 // 0: fp16 fragments (forward stream), 1: bf16 fragments (dgrad stream)
     int32_t is_bwd;               // 1: this is the dgrad (transposed) stream
+    int32_t reserved_flags;       // dgrad stream: bit 0 = carries the tiles for the gradient w.r.t. the rays
     int32_t n_emb_xyz, nkp;       // nkp = ceil((6*n_emb_xyz+3)/16)
     int32_t has_a, has_t, n_a, n_tau;
     int32_t n_rt, n_rt_sigma, n_rt_static;
@@ -110,7 +111,7 @@ extern "C" {
 struct nfl_field_desc;
 // returns 0 or a negative NFL_E* code
 int nfl_plan_fill(const struct nfl_field_desc* desc, int prec, struct NflPlan* plan);
-int nfl_plan_fill_bwd(const struct nfl_field_desc* desc, struct NflPlan* plan);
+int nfl_plan_fill_bwd(const struct nfl_field_desc* desc, int rays_grad, struct NflPlan* plan);
 #ifdef __cplusplus
 }
 #endif

@@ -104,15 +104,17 @@ NFL_DEV void nfl_turns(float x, float& th, float& tl) {
 
 // feature f of [x | sin(2^0 x) | cos(2^0 x) | sin(2^1 x) ...] (3 columns per block);
 // f, N compile-time after unrolling, coordinates as turns (th, tl) + raw value
+// `pw` = per-frequency weights (LDS, broadcast reads): all ones, or the BARF coarse-to-fine weights
+// of reference models/nerf.py:47-75 (computed on the host exactly as the reference does)
 template <int N>
-NFL_DEV float nfl_pe_feature(int f, const float (&raw)[3], const float (&th)[3], const float (&tl)[3]) {
+NFL_DEV float nfl_pe_feature(int f, const float (&raw)[3], const float (&th)[3], const float (&tl)[3], const float* pw) {
     if (f < 3) return raw[f];
     if (f >= 6 * N + 3) return 0.f;
     const int g = f - 3, k = g / 6, rem = g % 6, t = rem / 3, c = rem % 3;
     const float sc = (float)(1 << k);
     float r = __builtin_amdgcn_fractf(th[c] * sc) + tl[c] * sc;      // 2^k scaling is exact
     if (t) r += 0.25f;                                                // cos(y) = sin(y + pi/2)
-    return nfl_sin_rev(r);
+    return pw[k] * nfl_sin_rev(r);
 }
 
 template <int NP, class V8>
@@ -139,15 +141,15 @@ NFL_DEV void nfl_stash8(const float (&v)[8], char* dst) {
 // instruction stream is uniform.
 template <int N, int NP>
 NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th)[3], const float (&tl)[3],
-                          h8 (&dst)[NP], char* stash = nullptr) {
+                          const float* pw, h8 (&dst)[NP], char* stash = nullptr) {
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int f0 = 16 * ks + j, f1 = f0 + 8;
         // select the feature descriptor by lane half, then evaluate once
         if (f0 < 3 || f0 >= 6 * N + 3 || f1 >= 6 * N + 3) {
-            const float v0 = nfl_pe_feature<N>(f0, raw, th, tl);
-            const float v1 = nfl_pe_feature<N>(f1, raw, th, tl);
+            const float v0 = nfl_pe_feature<N>(f0, raw, th, tl, pw);
+            const float v1 = nfl_pe_feature<N>(f1, raw, th, tl, pw);
             v[j] = h ? v1 : v0;
         } else {
             const int g0 = f0 - 3, g1 = f1 - 3;
@@ -157,7 +159,7 @@ NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th
             const float tlc = h ? tl[c1] : tl[c0];
             const float ph = h ? 0.25f * t1 : 0.25f * t0;
             const float r = __builtin_amdgcn_fractf(thc * sc) + tlc * sc + ph;
-            v[j] = nfl_sin_rev(r);
+            v[j] = (h ? pw[k1] : pw[k0]) * nfl_sin_rev(r);
         }
     }
     nfl_split8<NP>(v, dst);
@@ -455,7 +457,7 @@ struct NflRenderCfg {
     static constexpr int LDS_RING = 3 * SLOT;
     static constexpr int LDS_BIAS = NFL_MAX_RT * 32 * 4;
     static constexpr int LDS_REC = (NSLOT + 2) * NFL_REC * 4;
-    static constexpr int LDS_CHK = (NFL_MAX_CHUNKS + 8) * 4;
+    static constexpr int LDS_CHK = (NFL_MAX_CHUNKS + 8 + 32) * 4;     // chunk offsets + 32 positional-encoding weights
     static constexpr int LDS_BYTES = LDS_RING + LDS_BIAS + LDS_REC + LDS_CHK;
 };
 
@@ -468,6 +470,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
     float* const bias_lds = reinterpret_cast<float*>(smem);
     float* const rec_lds = reinterpret_cast<float*>(smem + C::LDS_BIAS);   // [NSLOT] segment records, then carry[2]
     int* const chk_lds = reinterpret_cast<int*>(smem + C::LDS_BIAS + C::LDS_REC);
+    float* const pw_lds = reinterpret_cast<float*>(chk_lds + NFL_MAX_CHUNKS + 8);   // [0,16): xyz freqs, [16,32): dir freqs
 
     const nfl_pass_args& a = A.a;
     const int tid = threadIdx.x;
@@ -487,6 +490,8 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         const float* bg = reinterpret_cast<const float*>(A.packed + A.bias_off);
         for (int i = tid; i < A.n_rt * 32; i += 256) bias_lds[i] = bg[i];
         for (int i = tid; i <= A.n_chunks; i += 256) chk_lds[i] = A.plan->chunk_off[i];
+        if (tid < 16) pw_lds[tid] = (a.d_pe_w_xyz && tid < NFX) ? a.d_pe_w_xyz[tid] : 1.f;
+        else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid < 20) ? a.d_pe_w_dir[tid - 16] : 1.f;
     }
     __syncthreads();
 
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             for (int k = 0; k < 3; ++k) nfl_turns(raw[k], th[k], tl[k]);
 #pragma unroll
             for (int ks = 0; ks < NKP; ++ks) {
-                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, P[ks][cb], STASH ? st[cb] + ks * 1024 : nullptr);
+                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, pw_lds, P[ks][cb], STASH ? st[cb] + ks * 1024 : nullptr);
                 __builtin_amdgcn_sched_barrier(0);      // bound the register pressure of the encoder
             }
         }
@@ -581,9 +586,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         nfl_turns(raw[k], th[k], tl[k]);
                     }
                     char* sd = STASH ? st[cb] + nfl_act_d(NKP) * 1024 : nullptr;
-                    nfl_pe_kstep<4, NP>(0, h, raw, th, tl, D[0][cb], sd);
+                    nfl_pe_kstep<4, NP>(0, h, raw, th, tl, pw_lds + 16, D[0][cb], sd);
                     __builtin_amdgcn_sched_barrier(0);
-                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, D[1][cb], STASH ? sd + 1024 : nullptr);
+                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, pw_lds + 16, D[1][cb], STASH ? sd + 1024 : nullptr);
                     __builtin_amdgcn_sched_barrier(0);
                     if (A.has_a) {
                         const float* ap = a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;

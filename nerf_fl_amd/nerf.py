@@ -8,6 +8,8 @@ the fused HIP kernel.  forward() is provided only so code that calls a module
 directly (reference models/nerf.py:153-212, 19-32) keeps working; it is plain
 PyTorch and not on the measured path.
 """
+import math
+
 import torch
 from torch import nn
 
@@ -33,6 +35,42 @@ class PosEmbedding(nn.Module):
         return torch.cat(parts, -1)
 
 
+class BarfPosEmbedding(PosEmbedding):
+    """Coarse-to-fine (BARF) variant used with learnable poses (reference models/nerf.py:35-77,
+    created by train.py:42-44 as BarfPosEmbedding(N-1, N, 4, 8)).  The per-frequency weight is a
+    literal restatement of the reference, including its quirks: alpha = N_freqs / epoch inside
+    (epoch_start, epoch_end], N_freqs after, 0 before, and alpha is compared with the frequency
+    VALUE 2^k rather than with its index."""
+
+    def __init__(self, max_logscale, N_freqs, epoch_start, epoch_end, logscale=True):
+        super().__init__(max_logscale, N_freqs, logscale)
+        self.epoch_start, self.epoch_end = epoch_start, epoch_end
+
+    def barf_weight(self, freq, epoch):
+        freq = float(freq)
+        if self.epoch_start < epoch <= self.epoch_end:
+            alpha = self.N_freqs / epoch
+        elif epoch > self.epoch_end:
+            alpha = float(self.N_freqs)
+        else:
+            alpha = 0.0
+        if alpha < freq:
+            return 0.0
+        if alpha - freq < 1:
+            return float((1 - torch.cos(torch.tensor((alpha - freq) * math.pi, dtype=torch.float32))) / 2)
+        return 1.0
+
+    def weights(self, epoch):
+        return torch.tensor([self.barf_weight(f, epoch) for f in self.freqs], dtype=torch.float32)
+
+    def forward(self, x, epoch):
+        parts = [x]
+        for k, w in enumerate(self.weights(epoch).tolist()):
+            y = x * float(2 ** k)
+            parts += [w * torch.sin(y), w * torch.cos(y)]
+        return torch.cat(parts, -1)
+
+
 class NeRF(nn.Module):
     """Parameter container with the reference's layer names and shapes
     (models/nerf.py:81-151): 8x256 trunk with the encoded position re-read at
@@ -44,11 +82,9 @@ class NeRF(nn.Module):
         super().__init__()
         if D != 8 or W != 256 or tuple(skips) != (4,):
             raise NotImplementedError("the HIP renderer is built for D=8, W=256, skips=[4]")
-        if refine_pose:
-            raise NotImplementedError("BARF-weighted encoding (--refine_pose) is not built yet")
         self.typ, self.D, self.W, self.skips = typ, D, W, list(skips)
         self.in_channels_xyz, self.in_channels_dir = in_channels_xyz, in_channels_dir
-        self.refine_pose = False
+        self.refine_pose = bool(refine_pose)      # render_rays then expects BarfPosEmbedding embeddings + current_epoch
         self.encode_appearance = False if typ == "coarse" else encode_appearance
         self.in_channels_a = in_channels_a if encode_appearance else 0
         self.encode_transient = False if typ == "coarse" else encode_transient

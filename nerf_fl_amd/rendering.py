@@ -80,8 +80,6 @@ class _PackedField:
             beta_min=float(model.beta_min), reserved=0)
         if model.in_channels_xyz != 6 * n_emb_xyz + 3 or model.in_channels_dir != 6 * n_emb_dir + 3:
             raise ValueError("embedding widths do not match the model's in_channels_xyz / in_channels_dir")
-        if getattr(model, "refine_pose", False):
-            raise NotImplementedError("BARF-weighted positional encoding (--refine_pose) is not built yet")
         nbytes = L.nfl_plan_bytes(C.byref(self.desc))
         self.h_plan = C.create_string_buffer(nbytes)
         _lib.check(L.nfl_plan_build(C.byref(self.desc), prec, self.h_plan, nbytes), "nfl_plan_build")
@@ -90,8 +88,7 @@ class _PackedField:
         self.packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=device)
         self.key = None
         # dgrad stream (transposed weights, bf16 hi+lo); built lazily on the first training forward
-        self.h_bplan = self.d_bplan = self.bpacked = None
-        self.bkey = None
+        self.bplans = {}          # rays_grad -> dict(h, d, packed, nbytes, key)
         self.wplans = {}          # use_transient -> (host blob, device copy) of the wgrad job list
 
     def wgrad_plan(self, use_t):
@@ -112,21 +109,24 @@ class _PackedField:
                 out.append((i, params[name + ".weight"], params[name + ".bias"]))
         return out
 
-    def ensure_bwd_packed(self):
+    def ensure_bwd_packed(self, rays_grad=False):
+        """dgrad stream (transposed weights, bf16 hi+lo) for the current parameters."""
         L = _lib.lib()
-        if self.h_bplan is None:
+        rg = int(bool(rays_grad))
+        if rg not in self.bplans:
             nbytes = L.nfl_plan_bytes(C.byref(self.desc))
-            self.h_bplan = C.create_string_buffer(nbytes)
-            _lib.check(L.nfl_bwd_plan_build(C.byref(self.desc), self.h_bplan, nbytes), "nfl_bwd_plan_build")
-            self.d_bplan = torch.frombuffer(bytearray(self.h_bplan.raw), dtype=torch.uint8).to(self.device)
-            self.bpacked_bytes = L.nfl_bwd_packed_bytes(C.byref(self.desc))
-            self.bpacked = torch.empty(self.bpacked_bytes, dtype=torch.uint8, device=self.device)
-        if self.bkey == self.key:
-            return
-        fp, _keep = self._field_params()
-        _lib.check(L.nfl_pack_field(self.h_bplan, _ptr(self.d_bplan), C.byref(fp), _ptr(self.bpacked),
-                                    self.bpacked_bytes, _stream()), "nfl_pack_field(bwd)")
-        self.bkey = self.key
+            h = C.create_string_buffer(nbytes)
+            _lib.check(L.nfl_bwd_plan_build(C.byref(self.desc), rg, h, nbytes), "nfl_bwd_plan_build")
+            pb = L.nfl_bwd_packed_bytes(C.byref(self.desc), rg)
+            self.bplans[rg] = dict(h=h, d=torch.frombuffer(bytearray(h.raw), dtype=torch.uint8).to(self.device),
+                                   packed=torch.empty(pb, dtype=torch.uint8, device=self.device), nbytes=pb, key=None)
+        bp = self.bplans[rg]
+        if bp["key"] != self.key:
+            fp, _keep = self._field_params()
+            _lib.check(L.nfl_pack_field(bp["h"], _ptr(bp["d"]), C.byref(fp), _ptr(bp["packed"]), bp["nbytes"],
+                                        _stream()), "nfl_pack_field(bwd)")
+            bp["key"] = self.key
+        return bp
 
     def _field_params(self):
         params = dict(self.model_ref().named_parameters())
@@ -185,7 +185,8 @@ def _n_freqs(emb):
 
 def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, perturb=0.0, use_disp=False,
               noise=None, noise_std=0.0, a_emb=None, t_emb=None, view_dir=None, sigma_only=False,
-              white_back=False, test_extras=False, want_rgb=True, want_z=False, field_raw=False, stash=False):
+              white_back=False, test_extras=False, want_rgb=True, want_z=False, field_raw=False, stash=False,
+              pe_w_xyz=None, pe_w_dir=None):
     R = rays.shape[0]
     dev = rays.device
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -224,6 +225,7 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     a.d_depth_transient_only = _ptr(out.get("depth_transient_only"))
     a.d_field_raw = _ptr(out.get("field_raw"))
     a.d_act_stash = _ptr(out.get("act_stash"))
+    a.d_pe_w_xyz, a.d_pe_w_dir = _ptr(pe_w_xyz), _ptr(pe_w_dir)
     _lib.check(_lib.lib().nfl_render_pass(field.h_plan, _ptr(field.d_plan), _ptr(field.packed), C.byref(a), _stream()),
                "nfl_render_pass")
     return out
@@ -239,7 +241,7 @@ def _forward(cfg, rays, a_emb, t_emb, train):
     oc = _run_pass(f_c, rays, S, lin=_linspace(S, dev), perturb_rand=cfg["perturb_rand"], perturb=cfg["perturb"],
                    use_disp=cfg["use_disp"], noise=cfg["noise_c"], noise_std=cfg["noise_std"],
                    view_dir=cfg["view_dir"], sigma_only=test_time, white_back=cfg["white_back"],
-                   want_z=I > 0 or train, field_raw=raw, stash=train)
+                   want_z=I > 0 or train, field_raw=raw, stash=train, pe_w_xyz=cfg["pe_w_xyz"], pe_w_dir=cfg["pe_w_dir"])
     result["weights_coarse"] = oc["weights"]
     result["opacity_coarse"] = oc["opacity"]
     if not test_time:
@@ -258,7 +260,8 @@ def _forward(cfg, rays, a_emb, t_emb, train):
         use_t = cfg["use_t"]
         of = _run_pass(f_f, rays, F, z=z_fine, noise=cfg["noise_f"], noise_std=cfg["noise_std"], a_emb=a_emb,
                        t_emb=t_emb if use_t else None, view_dir=cfg["view_dir"], white_back=cfg["white_back"],
-                       test_extras=test_time, field_raw=raw, stash=train)
+                       test_extras=test_time, field_raw=raw, stash=train, pe_w_xyz=cfg["pe_w_xyz"],
+                       pe_w_dir=cfg["pe_w_dir"])
         result["weights_fine"] = of["weights"]
         result["opacity_fine"] = of["opacity"]
         if use_t:
@@ -292,7 +295,7 @@ def _g(grads, keys, name):
     return None if g is None else g.contiguous()
 
 
-def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents):
+def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=None):
     """One pass (coarse or fine) of the hand-written backward.  Returns (flat fp32 parameter
     gradient arena views per parameter, g_a_emb, g_t_emb)."""
     L = _lib.lib()
@@ -325,8 +328,11 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents):
     da.d_head_grads, da.d_act_stash, da.d_grad_stash = _ptr(head), _ptr(st["act"]), _ptr(grad_stash)
     da.n_rays, da.n_samples, da.use_transient = R, N, int(use_t)
     da.d_g_a_emb, da.d_g_t_emb = _ptr(g_a), _ptr(g_t)
-    _lib.check(L.nfl_mlp_dgrad(field.h_bplan, _ptr(field.d_bplan), _ptr(field.bpacked), C.byref(da), _stream()),
-               "nfl_mlp_dgrad")
+    if g_rays is not None:
+        da.d_g_rays, da.d_rays, da.d_z = _ptr(g_rays), _ptr(rays), _ptr(st["z"])
+        da.d_pe_w_xyz, da.d_pe_w_dir = _ptr(cfg["pe_w_xyz"]), _ptr(cfg["pe_w_dir"])
+    bp = field.ensure_bwd_packed(cfg["rays_grad"])
+    _lib.check(L.nfl_mlp_dgrad(bp["h"], _ptr(bp["d"]), _ptr(bp["packed"]), C.byref(da), _stream()), "nfl_mlp_dgrad")
 
     plist = field.param_list()
     arena = torch.zeros(sum(w.numel() + b.numel() for _, w, b in plist), dtype=torch.float32, device=dev)
@@ -352,12 +358,13 @@ class _RenderRaysFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, rays, a_emb, t_emb, *params):
+        rays = _f32c(rays, "rays")
         result, saved = _forward(cfg, rays, None if a_emb is None else _f32c(a_emb, "a_embedded"),
                                  None if t_emb is None else _f32c(t_emb, "t_embedded"), train=True)
-        cfg["f_c"].ensure_bwd_packed()
+        cfg["f_c"].ensure_bwd_packed(cfg["rays_grad"])
         cfg["f_c"].wgrad_plan(False)
         if cfg["f_f"] is not None:
-            cfg["f_f"].ensure_bwd_packed()
+            cfg["f_f"].ensure_bwd_packed(cfg["rays_grad"])
             cfg["f_f"].wgrad_plan(cfg["use_t"])
         keys = [k for k in result if not k.startswith("_field_raw") and k != "_z_fine"]
         ctx.cfg, ctx.keys, ctx.saved, ctx.rays = cfg, keys, saved, rays
@@ -371,14 +378,15 @@ class _RenderRaysFn(torch.autograd.Function):
         with torch.cuda.device(rays.device):
             out = []
             g_a = g_t = None
-            vc, _, _ = _backward_pass(cfg["f_c"], rays, saved["coarse"], "coarse", keys, grads, cfg, False)
+            g_rays = torch.zeros_like(rays) if cfg["rays_grad"] else None
+            vc, _, _ = _backward_pass(cfg["f_c"], rays, saved["coarse"], "coarse", keys, grads, cfg, False, g_rays)
             out += vc
             if cfg["f_f"] is not None:
-                vf, g_a, g_t = _backward_pass(cfg["f_f"], rays, saved["fine"], "fine", keys, grads, cfg, True)
+                vf, g_a, g_t = _backward_pass(cfg["f_f"], rays, saved["fine"], "fine", keys, grads, cfg, True, g_rays)
                 out += vf
         ga = g_a if (ctx.a_emb is not None and ctx.needs_input_grad[2]) else None
         gt = g_t if (ctx.t_emb is not None and ctx.needs_input_grad[3]) else None
-        return (None, None, ga, gt, *out)
+        return (None, g_rays if ctx.needs_input_grad[1] else None, ga, gt, *out)
 
 
 def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, perturb=0, noise_std=1,
@@ -386,9 +394,9 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
     """See the reference docstring (models/rendering.py:63-81); `chunk` is accepted and
     ignored -- the fused kernel never materialises per-sample tensors, so there is
     nothing to chunk."""
-    if isinstance(rays, torch.Tensor) and rays.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("gradients w.r.t. rays (--refine_pose) are not built yet")
-    rays = _f32c(rays[:, :8] if rays.shape[1] > 8 else rays, "rays")
+    rays_in = rays[:, :8] if rays.shape[1] > 8 else rays
+    rays_grad = bool(isinstance(rays_in, torch.Tensor) and rays_in.requires_grad and torch.is_grad_enabled())
+    rays = _f32c(rays_in, "rays")
     if rays.dim() != 2 or rays.shape[1] != 8:
         raise ValueError("rays must be (N_rays, 8): origin, direction, near, far")
     R, dev = rays.shape[0], rays.device
@@ -400,7 +408,18 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         cfg = dict(S=S, I=I, use_disp=bool(use_disp), perturb=float(perturb), noise_std=float(noise_std),
                    white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
                    view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
-                   use_t=False, f_f=None)
+                   use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None)
+        if getattr(models["coarse"], "refine_pose", False):
+            # BARF (reference rendering.py:105-108, 235-238): coarse-to-fine weights of both encodings
+            epoch = kwargs.get("current_epoch")
+            if epoch is None:
+                raise KeyError("current_epoch")
+            cfg["pe_w_xyz"] = embeddings["xyz"].weights(epoch).to(dev) if hasattr(embeddings["xyz"], "weights") else \
+                torch.tensor([float(embeddings["xyz"].barf_weight(f, epoch)) for f in embeddings["xyz"].freqs], device=dev)
+            cfg["pe_w_dir"] = embeddings["dir"].weights(epoch).to(dev) if hasattr(embeddings["dir"], "weights") else \
+                torch.tensor([float(embeddings["dir"].barf_weight(f, epoch)) for f in embeddings["dir"].freqs], device=dev)
+        if rays_grad and kwargs.get("view_dir") is not None:
+            raise NotImplementedError("gradient w.r.t. rays with a separate view_dir")
         if kwargs.get("view_dir") is not None:
             cfg["view_dir"] = _f32c(kwargs["view_dir"], "view_dir", (R, 3))
         cfg["f_c"] = _field(models["coarse"], n_xyz, n_dir, dev)
@@ -439,12 +458,12 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                 cfg["noise_f"] = nf if noise_std != 0 else None
 
         needs_grad = torch.is_grad_enabled() and (
-            any(p.requires_grad for p in params)
+            rays_grad or any(p.requires_grad for p in params)
             or any(t is not None and t.requires_grad for t in (a_emb, t_emb)))
         if needs_grad:
             if test_time:
                 raise RuntimeError("test_time=True is an inference mode; call it under torch.no_grad()")
-            outs = _RenderRaysFn.apply(cfg, rays, a_emb, t_emb, *params)
+            outs = _RenderRaysFn.apply(cfg, rays_in if rays_grad else rays, a_emb, t_emb, *params)
             keys = [k for k in _result_keys(cfg)]
             return dict(zip(keys, outs))
         a_c = None if a_emb is None else _f32c(a_emb, "a_embedded")

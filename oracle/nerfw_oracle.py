@@ -139,15 +139,38 @@ def make_embedding_table(n_vocab: int, dim: int, seed: int) -> Tensor:
 # --------------------------------------------------------------------------
 # A1: positional encoding          (reference models/nerf.py:6-32)
 # --------------------------------------------------------------------------
-def posenc(x: Tensor, n_freqs: int) -> Tensor:
+def posenc(x: Tensor, n_freqs: int, weights: Optional[Tensor] = None) -> Tensor:
     """[x | sin(2^0 x) | cos(2^0 x) | ... ]: x first, sin before cos,
-    frequency-major, 3 columns per block."""
+    frequency-major, 3 columns per block.  `weights` (n_freqs,) = BARF coarse-to-fine
+    weights of the sin/cos blocks (reference models/nerf.py:61-77)."""
     cols = [x]
     for k in range(n_freqs):
         arg = x * float(2 ** k)          # power-of-two scaling: exact in fp32
-        cols.append(arg.sin())
-        cols.append(arg.cos())
+        w = 1.0 if weights is None else float(weights[k])
+        cols.append(w * arg.sin() if weights is not None else arg.sin())
+        cols.append(w * arg.cos() if weights is not None else arg.cos())
     return torch.cat(cols, dim=-1)
+
+
+def barf_weights(n_freqs: int, epoch, epoch_start: int = 4, epoch_end: int = 8) -> Tensor:
+    """Per-frequency weights of the reference's BarfPosEmbedding (models/nerf.py:47-59, constants
+    train.py:43-44), restated literally: alpha is compared with the frequency VALUE 2^k."""
+    if epoch_start < epoch <= epoch_end:
+        alpha = n_freqs / epoch
+    elif epoch > epoch_end:
+        alpha = float(n_freqs)
+    else:
+        alpha = 0.0
+    out = []
+    for k in range(n_freqs):
+        freq = float(2 ** k)
+        if alpha < freq:
+            out.append(0.0)
+        elif alpha - freq < 1:
+            out.append(float((1 - torch.cos(torch.tensor((alpha - freq) * np.pi, dtype=torch.float32))) / 2))
+        else:
+            out.append(1.0)
+    return torch.tensor(out, dtype=torch.float32)
 
 
 # --------------------------------------------------------------------------
@@ -305,9 +328,9 @@ def composite(typ: str, z: Tensor, f: Dict[str, Tensor], *, noise: Optional[Tens
 # --------------------------------------------------------------------------
 # render_rays                      (reference models/rendering.py:49-289)
 # --------------------------------------------------------------------------
-def _eval_field(spec, P, xyz, dir_enc, a_emb, t_emb, sigma_only):
+def _eval_field(spec, P, xyz, dir_enc, a_emb, t_emb, sigma_only, pe_w_xyz=None):
     R, N = xyz.shape[:2]
-    enc = posenc(xyz.reshape(-1, 3), spec.n_emb_xyz)
+    enc = posenc(xyz.reshape(-1, 3), spec.n_emb_xyz, pe_w_xyz)
     if sigma_only:
         o = field_forward(spec, P, enc, sigma_only=True)
     else:
@@ -329,16 +352,17 @@ def render_rays(spec_c: FieldSpec, P_c: Dict[str, Tensor],
                 output_transient: bool = True, view_dir: Optional[Tensor] = None,
                 perturb_rand: Optional[Tensor] = None, noise_coarse: Optional[Tensor] = None,
                 u: Optional[Tensor] = None, noise_fine: Optional[Tensor] = None,
-                return_z: bool = False) -> Dict[str, Tensor]:
+                return_z: bool = False, pe_w_xyz: Optional[Tensor] = None,
+                pe_w_dir: Optional[Tensor] = None) -> Dict[str, Tensor]:
     R = rays.shape[0]
     o, d = rays[:, 0:3], rays[:, 3:6]
     near, far = rays[:, 6:7], rays[:, 7:8]
-    dir_enc = posenc(d if view_dir is None else view_dir, spec_c.n_emb_dir)
+    dir_enc = posenc(d if view_dir is None else view_dir, spec_c.n_emb_dir, pe_w_dir)
     zeros = lambda n: torch.zeros(R, n)
 
     z = coarse_depths(near, far, n_samples, use_disp, perturb, perturb_rand)
     xyz = o[:, None, :] + d[:, None, :] * z[..., None]
-    fc = _eval_field(spec_c, P_c, xyz, dir_enc, None, None, sigma_only=test_time)
+    fc = _eval_field(spec_c, P_c, xyz, dir_enc, None, None, sigma_only=test_time, pe_w_xyz=pe_w_xyz)
     res = composite("coarse", z, fc, noise=noise_coarse if noise_coarse is not None else zeros(n_samples),
                     noise_std=noise_std, white_back=white_back, test_time=test_time,
                     beta_min=spec_c.beta_min)
@@ -350,7 +374,8 @@ def render_rays(spec_c: FieldSpec, P_c: Dict[str, Tensor],
         z = torch.sort(torch.cat([z, zs], dim=1), dim=1)[0]
         xyz = o[:, None, :] + d[:, None, :] * z[..., None]
         use_t = bool(output_transient and spec_f.encode_transient)
-        ff = _eval_field(spec_f, P_f, xyz, dir_enc, a_emb, t_emb if use_t else None, sigma_only=False)
+        ff = _eval_field(spec_f, P_f, xyz, dir_enc, a_emb, t_emb if use_t else None, sigma_only=False,
+                         pe_w_xyz=pe_w_xyz)
         n_f = n_samples + n_importance
         res.update(composite("fine", z, ff, noise=noise_fine if noise_fine is not None else zeros(n_f),
                              noise_std=noise_std, white_back=white_back, test_time=test_time,

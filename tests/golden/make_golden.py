@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 sys.path.insert(0, "/root/reference")
 
-from models.nerf import NeRF, PosEmbedding            # noqa: E402  (reference)
+from models.nerf import NeRF, PosEmbedding, BarfPosEmbedding   # noqa: E402  (reference)
 from models.rendering import render_rays, sample_pdf  # noqa: E402  (reference)
 from losses import loss_dict                           # noqa: E402  (reference)
 
@@ -32,11 +32,11 @@ from oracle import nerfw_oracle as orc                 # noqa: E402
 torch.set_num_threads(8)
 
 
-def ref_field(spec: orc.FieldSpec, seed: int, regime: str):
+def ref_field(spec: orc.FieldSpec, seed: int, regime: str, refine_pose: bool = False):
     m = NeRF(spec.typ, in_channels_xyz=spec.c_xyz, in_channels_dir=spec.c_dir,
              encode_appearance=spec.encode_appearance, in_channels_a=spec.n_a,
              encode_transient=spec.encode_transient, in_channels_t=spec.n_tau,
-             beta_min=spec.beta_min)
+             beta_min=spec.beta_min, refine_pose=refine_pose)
     P = orc.make_field_params(spec, seed, regime)
     missing = m.load_state_dict(P, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
@@ -139,26 +139,32 @@ def g3_sample_pdf():
 def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, use_disp=False,
                 perturb=0.0, noise_std=0.0, test_time=False, n_vocab=20, kwargs_mode="ts",
                 output_transient=None, grads=False, rays_grad=False, near=2.0, far=6.0, seed=11,
-                n_emb_xyz=10):
+                n_emb_xyz=10, barf_epoch=None):
     """fine: None | 'base' | 'a' | 'at'."""
     spec_c = orc.FieldSpec("coarse", n_emb_xyz=n_emb_xyz)
-    mc = ref_field(spec_c, seed, regime)
+    barf = barf_epoch is not None
+    mc = ref_field(spec_c, seed, regime, refine_pose=barf)
     models = {"coarse": mc}
-    embeddings = {"xyz": PosEmbedding(n_emb_xyz - 1, n_emb_xyz), "dir": PosEmbedding(3, 4)}
+    if barf:        # train.py:42-44
+        embeddings = {"xyz": BarfPosEmbedding(n_emb_xyz - 1, n_emb_xyz, 4, 8), "dir": BarfPosEmbedding(3, 4, 4, 8)}
+    else:
+        embeddings = {"xyz": PosEmbedding(n_emb_xyz - 1, n_emb_xyz), "dir": PosEmbedding(3, 4)}
     cfg = dict(R=R, S=S, I=I, fine=fine, regime=regime, white_back=white_back, use_disp=use_disp,
                perturb=perturb, noise_std=noise_std, test_time=test_time, n_vocab=n_vocab,
                kwargs_mode=kwargs_mode, output_transient=output_transient, seed=seed,
-               n_emb_xyz=n_emb_xyz, beta_min=0.1)
+               n_emb_xyz=n_emb_xyz, beta_min=0.1, barf_epoch=barf_epoch)
     spec_f = None
     if fine is not None:
         spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, encode_appearance=fine in ("a", "at"),
                                encode_transient=fine == "at", beta_min=0.1)
-        models["fine"] = ref_field(spec_f, seed + 1, regime)
+        models["fine"] = ref_field(spec_f, seed + 1, regime, refine_pose=barf)
     rays = orc.make_rays(R, seed + 2, near, far)
     rng = np.random.default_rng(seed + 3)
     ts = torch.from_numpy(rng.integers(0, n_vocab, size=R).astype(np.int64))
     arrays = {"rays": rays, "ts": ts}
     kwargs = {}
+    if barf:
+        kwargs["current_epoch"] = barf_epoch
     a_emb = t_emb = None
     if spec_f is not None and spec_f.encode_appearance:
         table_a = orc.make_embedding_table(n_vocab, 48, seed + 4)
@@ -186,6 +192,7 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
     for p in list(mc.parameters()) + (list(models["fine"].parameters()) if fine else []):
         p.requires_grad_(grads)
 
+    torch.manual_seed(1000 + seed + R + S + I)     # the captured draws are part of the fixture: keep them reproducible
     with CaptureRandom() as cap:
         ctx = torch.enable_grad() if grads else torch.no_grad()
         with ctx:
@@ -270,6 +277,11 @@ def main():
     render_case("g12_stoch_nerfw", R=64, S=64, I=64, fine="at", white_back=True, perturb=1.0, noise_std=1.0)
     render_case("g12_stoch_grad", R=64, S=64, I=64, fine="base", white_back=True, perturb=1.0, noise_std=1.0,
                 grads=True)
+    # G14: learnable-pose mode: BARF-weighted encodings (epochs inside and after the ramp) + gradient w.r.t. rays
+    render_case("g14_barf_e6", R=32, S=32, I=32, fine="base", white_back=True, grads=True, rays_grad=True, barf_epoch=6)
+    render_case("g14_barf_e9", R=32, S=64, I=64, fine="at", white_back=False, grads=True, rays_grad=True, barf_epoch=9,
+                kwargs_mode="embedded")
+    render_case("g14_barf_e2_fwd", R=32, S=32, I=32, fine="base", white_back=True, barf_epoch=2)
 
 
 if __name__ == "__main__":

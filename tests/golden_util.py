@@ -78,4 +78,8 @@ def oracle_kwargs(cfg, arrays):
               test_time=cfg["test_time"], a_emb=a_emb, t_emb=t_emb,
               output_transient=True if cfg["output_transient"] is None else cfg["output_transient"])
     kw.update(random_inputs(cfg, arrays))
+    if cfg.get("barf_epoch") is not None:
+        kw["barf_epoch"] = cfg["barf_epoch"]
+        kw["pe_w_xyz"] = orc.barf_weights(spec_c.n_emb_xyz, cfg["barf_epoch"])
+        kw["pe_w_dir"] = orc.barf_weights(spec_c.n_emb_dir, cfg["barf_epoch"])
     return (spec_c, P_c, spec_f, P_f), kw

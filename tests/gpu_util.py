@@ -8,23 +8,34 @@ from oracle import nerfw_oracle as orc
 DEV = "cuda:0"
 
 
-def module_from(spec, P):
+def module_from(spec, P, refine_pose=False):
     m = NeRF(spec.typ, in_channels_xyz=spec.c_xyz, in_channels_dir=spec.c_dir,
              encode_appearance=spec.encode_appearance, in_channels_a=spec.n_a,
-             encode_transient=spec.encode_transient, in_channels_t=spec.n_tau, beta_min=spec.beta_min)
+             encode_transient=spec.encode_transient, in_channels_t=spec.n_tau, beta_min=spec.beta_min,
+             refine_pose=refine_pose)
     m.load_state_dict({k: v.detach().clone() for k, v in P.items()}, strict=True)
     return m.to(DEV)
+
+
+def make_embeddings(n_emb_xyz, barf):
+    if barf:
+        from nerf_fl_amd import BarfPosEmbedding
+        return {"xyz": BarfPosEmbedding(n_emb_xyz - 1, n_emb_xyz, 4, 8), "dir": BarfPosEmbedding(3, 4, 4, 8)}
+    return {"xyz": PosEmbedding(n_emb_xyz - 1, n_emb_xyz), "dir": PosEmbedding(3, 4)}
 
 
 def hip_render(specs, rays, kw, precision="f16x3", field_raw=False):
     """kw: the oracle_kwargs dict of golden_util (same semantics as oracle.render_rays)."""
     spec_c, P_c, spec_f, P_f = specs
     nerf_fl_amd.set_precision(precision)
-    models = {"coarse": module_from(spec_c, P_c)}
+    barf = kw.get("pe_w_xyz") is not None
+    models = {"coarse": module_from(spec_c, P_c, barf)}
     if spec_f is not None:
-        models["fine"] = module_from(spec_f, P_f)
-    emb = {"xyz": PosEmbedding(spec_c.n_emb_xyz - 1, spec_c.n_emb_xyz), "dir": PosEmbedding(3, 4)}
+        models["fine"] = module_from(spec_f, P_f, barf)
+    emb = make_embeddings(spec_c.n_emb_xyz, barf)
     extra = {}
+    if barf:
+        extra["current_epoch"] = kw["barf_epoch"]
     for k in ("perturb_rand", "noise_coarse", "u", "noise_fine"):
         if kw.get(k) is not None:
             extra[k] = kw[k].to(DEV)

@@ -53,10 +53,10 @@ def test_plan_structure(L):
     assert L.nfl_plan_build(C.byref(d), _lib.NFL_PREC_F16X3, buf, n) == 0
     assert L.nfl_plan_build(C.byref(d), _lib.NFL_PREC_F16X3, buf, 16) == -4          # NFL_ESMALL
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
-    magic, prec, nsplit, elem, is_bwd, nx, nkp, has_a, has_t = hdr[:9]
+    magic, prec, nsplit, elem, is_bwd, flags, nx, nkp, has_a, has_t = hdr[:10]
     assert magic == 0x4E464C31 and nsplit == 3 and nx == 10 and nkp == 4 and has_a == 1 and has_t == 1
-    assert elem == 0 and is_bwd == 0
-    n_rt, n_rt_sigma, n_rt_static, n_chunks, n_chunks_sigma, n_chunks_static, total_ks, ks_bytes = hdr[11:19]
+    assert elem == 0 and is_bwd == 0 and flags == 0
+    n_rt, n_rt_sigma, n_rt_static, n_chunks, n_chunks_sigma, n_chunks_static, total_ks, ks_bytes = hdr[12:20]
     assert (n_rt_sigma, n_rt_static, n_rt) == (65, 78, 95)
     assert (n_chunks_sigma, n_chunks_static, n_chunks) == (61, 74, 85)
     assert ks_bytes == 2048
@@ -72,14 +72,18 @@ def test_bwd_plan_structure(L):
     d = _lib.FieldDesc(10, 4, 1, 48, 1, 16, 0.1, 0)
     n = L.nfl_plan_bytes(C.byref(d))
     buf = C.create_string_buffer(n)
-    assert L.nfl_bwd_plan_build(C.byref(d), buf, n) == 0
+    assert L.nfl_bwd_plan_build(C.byref(d), 0, buf, n) == 0
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
-    assert hdr[3] == 1 and hdr[4] == 1            # bf16 fragments, dgrad stream
-    n_rt, n_chunks, total_ks = hdr[11], hdr[14], hdr[17]
+    assert hdr[3] == 1 and hdr[4] == 1 and hdr[5] == 0     # bf16 fragments, dgrad stream, no rays-gradient tiles
+    n_rt, n_chunks, total_ks = hdr[12], hdr[15], hdr[18]
     # one transposed row tile per chunk: transient 4+12+1, rgb^T 4, appearance rows 2, feat 8, h8 8, 7 trunk layers x 8
     assert n_rt == n_chunks == 17 + 4 + 2 + 8 + 8 + 56
     assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 16 + 8 * 17 + 56 * 16
-    assert L.nfl_bwd_packed_bytes(C.byref(d)) == total_ks * 2048 + n_rt * 128
+    assert L.nfl_bwd_packed_bytes(C.byref(d), 0) == total_ks * 2048 + n_rt * 128
+    # with the gradient w.r.t. the rays: + direction rows (1 tile, 8 ks) + encoded-position rows of layers 5 and 1 (2 x 2 tiles, 16 ks)
+    assert L.nfl_bwd_plan_build(C.byref(d), 1, buf, n) == 0
+    hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)
+    assert hdr2[5] == 1 and hdr2[12] == n_rt + 5 and hdr2[18] == total_ks + 8 + 4 * 16
     # stash sizes: per 32-sample segment 194 / 189 KiB (+ 4 KiB tail pad)
     assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 194 * 1024 + 4096
     assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == (8 * 4 + 1) * 189 * 1024 + 4096

@@ -12,7 +12,8 @@ from oracle import nerfw_oracle as orc
 
 pytestmark = pytest.mark.gpu
 GTOL = 2e-2
-CASES = ["g11_grad_cfg1", "g11_grad_cfg2", "g11_grad_cfg3", "g11_grad_cfg3_ts", "g12_stoch_grad"]
+CASES = ["g11_grad_cfg1", "g11_grad_cfg2", "g11_grad_cfg3", "g11_grad_cfg3_ts", "g12_stoch_grad",
+         "g11_grad_rays", "g14_barf_e6", "g14_barf_e9"]      # the last three also check d/d rays (learnable poses)
 
 
 def run_case(name):
@@ -23,11 +24,14 @@ def run_case(name):
     (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
     nerf_fl_amd.set_precision("f16x3")
     dev = gpu_util.DEV
-    models = {"coarse": gpu_util.module_from(spec_c, P_c)}
+    barf = cfg.get("barf_epoch") is not None
+    models = {"coarse": gpu_util.module_from(spec_c, P_c, barf)}
     if spec_f is not None:
-        models["fine"] = gpu_util.module_from(spec_f, P_f)
-    emb = {"xyz": PosEmbedding(spec_c.n_emb_xyz - 1, spec_c.n_emb_xyz), "dir": PosEmbedding(3, 4)}
+        models["fine"] = gpu_util.module_from(spec_f, P_f, barf)
+    emb = gpu_util.make_embeddings(spec_c.n_emb_xyz, barf)
     extra, leaves = {}, {}
+    if barf:
+        extra["current_epoch"] = cfg["barf_epoch"]
     for k in ("perturb_rand", "noise_coarse", "u", "noise_fine"):
         if kw.get(k) is not None:
             extra[k] = kw[k].to(dev)
@@ -44,7 +48,11 @@ def run_case(name):
                 e.weight.data.copy_(orc.make_embedding_table(cfg["n_vocab"], dim, cfg["seed"] + off))
                 emb[k] = e
                 leaves["table_" + k] = e.weight
-    res = render_rays(models, emb, a["rays"].to(dev), ts, cfg["S"], cfg["use_disp"], cfg["perturb"], cfg["noise_std"],
+    rays = a["rays"].to(dev)
+    if "grad.rays" in a:
+        rays.requires_grad_(True)
+        leaves["rays"] = rays
+    res = render_rays(models, emb, rays, ts, cfg["S"], cfg["use_disp"], cfg["perturb"], cfg["noise_std"],
                       cfg["I"], 32768, cfg["white_back"], False, **extra)
     assert list(res.keys()) == cfg["keys"]
     loss = sum(orc.nerfw_loss(res, a["target"].to(dev)).values())
@@ -62,7 +70,9 @@ def run_case(name):
 def compare(cfg, a, got):
     """yield (key, max abs err, max abs ref)"""
     for key, exp in a.items():
-        if key.startswith("grad.") and key != "grad.rays":
+        if key == "grad.rays":      # origin and direction columns; near/far carry no gradient here (they are data)
+            yield key, (got["rays"][:, :6] - exp[:, :6]).abs().max().item(), exp[:, :6].abs().max().item()
+        elif key.startswith("grad."):
             yield key, (got[key[5:]] - exp).abs().max().item(), exp.abs().max().item()
         elif key.startswith("gradrows."):
             yield key, (got[key[9:]][:4] - exp).abs().max().item(), exp.abs().max().item()
@@ -83,11 +93,3 @@ def test_gradients_vs_reference(name):
     assert not bad, f"{name}: {bad}"
 
 
-def test_rays_gradient_not_built():
-    import gpu_util
-    from nerf_fl_amd import NeRF, PosEmbedding, render_rays
-    models = {"coarse": NeRF("coarse").to(gpu_util.DEV)}
-    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
-    rays = orc.make_rays(8, 1).to(gpu_util.DEV).requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        render_rays(models, emb, rays, torch.zeros(8, dtype=torch.long, device=gpu_util.DEV), 8)

@@ -41,13 +41,14 @@ def test_g3_sample_pdf():
 
 
 RENDER = [n for n in gu.golden_names("g") if n[:2] in ("g4", "g5", "g6", "g7", "g8", "g9")
-          or n.startswith(("g10", "g12", "g13"))]
+          or n.startswith(("g10", "g12", "g13", "g14"))]
 
 
 @pytest.mark.parametrize("name", RENDER)
 def test_render_forward(name):
     cfg, a = gu.load(name)
     (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
+    kw.pop("barf_epoch", None)
     with torch.no_grad():
         res = orc.render_rays(spec_c, P_c, spec_f, P_f, a["rays"], **kw)
     assert list(res.keys()) == cfg["keys"], "dict key order must match the reference"
@@ -58,13 +59,14 @@ def test_render_forward(name):
         assert err <= TOL, f"{name}:{k} max abs err {err:.3e}"
 
 
-GRAD = gu.golden_names("g11_") + ["g12_stoch_grad"]
+GRAD = gu.golden_names("g11_") + ["g12_stoch_grad", "g14_barf_e6", "g14_barf_e9"]
 
 
 @pytest.mark.parametrize("name", GRAD)
 def test_render_gradients(name):
     cfg, a = gu.load(name)
     (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
+    kw.pop("barf_epoch", None)
     rays = a["rays"].clone()
     leaves = {}
     for tag, P in (("coarse", P_c), ("fine", P_f)):
