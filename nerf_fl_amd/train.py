@@ -1,0 +1,143 @@
+"""A thin training harness for the HIP renderer (the role of the reference's NeRFSystem +
+Lightning Trainer, train.py:33-241, without Lightning).
+
+What it keeps from the reference:
+  * modules and their checkpoint key prefixes -- `nerf_coarse.*`, `nerf_fine.*`, `embedding_a.*`,
+    `embedding_t.*` (train.py:51-76) -- so `utils.load_ckpt` (utils/__init__.py:67-88) and this
+    harness can exchange weights;
+  * Adam(lr, eps=1e-8) (utils/__init__.py:30-32), optional cosine / step decay per epoch
+    (utils/__init__.py:44-61), NerfWLoss (losses.py:18-50), PSNR = -10 log10(mse) (metrics.py:12-13).
+What it does differently, because the renderer is ~10^3 x faster than the data path around it:
+  * rays / colours / image ids live on the GPU as flat tensors; a batch is a slice of a device-side
+    permutation (no DataLoader workers, no per-item collation: train.py:144-149);
+  * rays are the upstream 8-column Blender contract (o, d, near, far) handed straight to render_rays;
+  * multi-GPU: every rank shuffles its own shard; gradients are averaged with one flat all-reduce.
+"""
+import math
+import os
+
+import torch
+from torch import nn
+
+from . import parallel
+from .nerf import NeRF, PosEmbedding
+from .rendering import render_rays
+
+__all__ = ["NerfWLoss", "psnr", "RayTrainer"]
+
+
+class NerfWLoss(nn.Module):
+    """Equation 13 of NeRF-W as the reference implements it (losses.py:18-50): c_l, f_l, b_l (+3), s_l."""
+
+    def __init__(self, coef=1.0, lambda_u=0.01):
+        super().__init__()
+        self.coef, self.lambda_u = coef, lambda_u
+
+    def forward(self, inputs, targets):
+        ret = {"c_l": 0.5 * ((inputs["rgb_coarse"] - targets) ** 2).mean()}
+        if "rgb_fine" in inputs:
+            if "beta" not in inputs:
+                ret["f_l"] = 0.5 * ((inputs["rgb_fine"] - targets) ** 2).mean()
+            else:
+                beta = inputs["beta"]
+                ret["f_l"] = ((inputs["rgb_fine"] - targets) ** 2 / (2 * beta.unsqueeze(1) ** 2)).mean()
+                ret["b_l"] = 3 + torch.log(beta).mean()
+                ret["s_l"] = self.lambda_u * inputs["transient_sigmas"].mean()
+        return {k: self.coef * v for k, v in ret.items()}
+
+
+def psnr(pred, gt):
+    return -10.0 * torch.log10(((pred - gt) ** 2).mean())
+
+
+class RayTrainer:
+    """Fit coarse+fine fields to (rays, rgbs, ts) tensors that are already on the device."""
+
+    def __init__(self, device, N_emb_xyz=10, N_emb_dir=4, N_samples=64, N_importance=64, use_disp=False,
+                 perturb=1.0, noise_std=1.0, white_back=True, encode_a=False, encode_t=False, N_vocab=100,
+                 N_a=48, N_tau=16, beta_min=0.1, lr=5e-4, batch_size=1024, lr_scheduler=None, num_epochs=16,
+                 decay_step=(20,), decay_gamma=0.1, seed=0):
+        self.dev = torch.device(device)
+        self.hp = dict(N_samples=N_samples, N_importance=N_importance, use_disp=use_disp, perturb=perturb,
+                       noise_std=noise_std, white_back=white_back, batch_size=batch_size)
+        torch.manual_seed(seed)
+        self.embeddings = {"xyz": PosEmbedding(N_emb_xyz - 1, N_emb_xyz), "dir": PosEmbedding(N_emb_dir - 1, N_emb_dir)}
+        self.modules = {}                                   # checkpoint prefix -> module (train.py:48-76)
+        if encode_a:
+            self.embeddings["a"] = self.modules["embedding_a"] = nn.Embedding(N_vocab, N_a).to(self.dev)
+        if encode_t:
+            self.embeddings["t"] = self.modules["embedding_t"] = nn.Embedding(N_vocab, N_tau).to(self.dev)
+        cx, cd = 6 * N_emb_xyz + 3, 6 * N_emb_dir + 3
+        self.models = {"coarse": NeRF("coarse", in_channels_xyz=cx, in_channels_dir=cd).to(self.dev)}
+        self.modules["nerf_coarse"] = self.models["coarse"]
+        if N_importance > 0:
+            self.models["fine"] = NeRF("fine", in_channels_xyz=cx, in_channels_dir=cd, encode_appearance=encode_a,
+                                       in_channels_a=N_a, encode_transient=encode_t, in_channels_t=N_tau,
+                                       beta_min=beta_min).to(self.dev)
+            self.modules["nerf_fine"] = self.models["fine"]
+        self.params = [p for m in self.modules.values() for p in m.parameters()]
+        self.opt = torch.optim.Adam(self.params, lr=lr, eps=1e-8)
+        if lr_scheduler == "cosine":
+            self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=num_epochs, eta_min=1e-8)
+        elif lr_scheduler == "steplr":
+            self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=list(decay_step), gamma=decay_gamma)
+        else:
+            self.sched = None
+        self.loss = NerfWLoss()
+        self.gen = torch.Generator(device=self.dev).manual_seed(seed + 1)
+
+    # ---- one optimisation step on a ready batch ------------------------------------------------
+    def step(self, rays, rgbs, ts):
+        hp = self.hp
+        self.opt.zero_grad(set_to_none=True)
+        res = render_rays(self.models, self.embeddings, rays, ts, hp["N_samples"], hp["use_disp"], hp["perturb"],
+                          hp["noise_std"], hp["N_importance"], 32768, hp["white_back"], False)
+        losses = self.loss(res, rgbs)
+        total = sum(losses.values())
+        total.backward()
+        parallel.all_reduce_gradients(self.params)
+        self.opt.step()
+        key = "rgb_fine" if "rgb_fine" in res else "rgb_coarse"
+        return total.detach(), psnr(res[key].detach(), rgbs)
+
+    # ---- one epoch over device-resident data (this rank's shard) -------------------------------
+    def fit_epoch(self, rays, rgbs, ts):
+        n, bs = rays.shape[0], self.hp["batch_size"]
+        perm = torch.randperm(n, device=self.dev, generator=self.gen)
+        log = []
+        for i in range(0, n - bs + 1, bs):
+            idx = perm[i:i + bs]
+            log.append(self.step(rays[idx], rgbs[idx], ts[idx]))
+        if self.sched is not None:
+            self.sched.step()
+        return torch.stack([torch.stack(x) for x in log]).mean(0).tolist() if log else [math.nan, math.nan]
+
+    @torch.no_grad()
+    def validate(self, rays, rgbs, ts, chunk=32768):
+        """Mean PSNR of a deterministic render (perturb 0, noise 0; train.py:176-210)."""
+        hp = self.hp
+        outs = []
+        for i in range(0, rays.shape[0], chunk):
+            res = render_rays(self.models, self.embeddings, rays[i:i + chunk], ts[i:i + chunk], hp["N_samples"],
+                              hp["use_disp"], 0, 0, hp["N_importance"], chunk, hp["white_back"], False)
+            outs.append(res["rgb_fine" if "rgb_fine" in res else "rgb_coarse"])
+        return float(psnr(torch.cat(outs), rgbs))
+
+    # ---- checkpoints with the reference's key prefixes -----------------------------------------
+    def state_dict(self):
+        return {f"{prefix}.{k}": v for prefix, m in self.modules.items() for k, v in m.state_dict().items()}
+
+    def load_state_dict(self, sd):
+        """Accepts this harness' checkpoints and Lightning checkpoints' `state_dict` (prefix-stripped per
+        module exactly as utils.extract_model_state_dict does)."""
+        sd = sd.get("state_dict", sd)
+        for prefix, m in self.modules.items():
+            sub = {k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}
+            m.load_state_dict(sub, strict=True)
+
+    def save(self, path, epoch=0):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save({"epoch": epoch, "state_dict": self.state_dict()}, path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.dev, weights_only=True))

@@ -19,7 +19,7 @@ m = NeRF("fine")
 m.load_state_dict(orc.make_field_params(orc.FieldSpec("fine"), 12, "sharp"))
 m = m.to(dev)
 f = rnd._field(m, 10, 4, dev)
-f.ensure_bwd_packed()
+bp = f.ensure_bwd_packed(False)
 rays = orc.make_rays(R, 100).to(dev)
 z = torch.sort(2 + 4 * torch.rand(R, F, device=dev), dim=1)[0]
 noise = torch.randn(R, F, device=dev)
@@ -61,7 +61,7 @@ if prec == "f16x3":
     da = _lib.DgradArgs()
     da.d_head_grads, da.d_act_stash, da.d_grad_stash = rnd._ptr(head), rnd._ptr(st["act"]), rnd._ptr(grad_stash)
     da.n_rays, da.n_samples, da.use_transient = R, F, 0
-    print("dgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_dgrad(f.h_bplan, rnd._ptr(f.d_bplan), rnd._ptr(f.bpacked), C.byref(da), rnd._stream()), "dg")))
+    print("dgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_dgrad(bp['h'], rnd._ptr(bp['d']), rnd._ptr(bp['packed']), C.byref(da), rnd._stream()), "dg")))
     plist = f.param_list()
     arena = torch.zeros(sum(w.numel() + b.numel() for _, w, b in plist), device=dev)
     fg = _lib.FieldGrads()
