@@ -457,6 +457,10 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                 nf = torch.randn(R, F, device=dev) if nf is None else _f32c(nf, "noise_fine", (R, F))
                 cfg["noise_f"] = nf if noise_std != 0 else None
 
+        if R == 0:          # nothing to launch: the reference returns empty tensors of the right shapes
+            shp = lambda k: ((0, S if k.endswith("coarse") else F) if k.startswith(("weights", "transient_sigmas"))
+                             else (0, 3) if "rgb" in k else (0,))
+            return {k: torch.empty(shp(k), dtype=torch.float32, device=dev) for k in _result_keys(cfg)}
         needs_grad = torch.is_grad_enabled() and (
             rays_grad or any(p.requires_grad for p in params)
             or any(t is not None and t.requires_grad for t in (a_emb, t_emb)))
