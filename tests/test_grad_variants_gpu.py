@@ -101,3 +101,53 @@ def test_gradients_vs_oracle_autograd(name):
         else:
             assert t_h.grad is None
     assert not bad, bad
+
+
+def test_learnable_pose_gradients_end_to_end():
+    """--refine_pose: (r, t) -> c2w -> rays -> BARF-encoded render -> loss; the pose gradients that come
+    back through the HIP backward's d/d rays match the CPU oracle + autograd."""
+    import gpu_util
+    from nerf_fl_amd import render_rays
+    from nerf_fl_amd.poses import LearnPose, get_ray_directions, get_rays
+    dev = gpu_util.DEV
+    H = W = 6
+    Kmat = torch.tensor([[7.0, 0, 3.0], [0, 7.0, 3.0], [0, 0, 1]])
+    dirs = get_ray_directions(H, W, Kmat).reshape(-1, 3)                       # 36 rays of one camera
+    init = torch.eye(4)[None].repeat(2, 1, 1)
+    init[:, :3, 3] = torch.tensor([[0.1, -0.1, 4.0], [0.3, 0.2, 4.2]])
+    cam = torch.tensor([0] * 18 + [1] * 18)
+    spec_c, spec_f = orc.FieldSpec("coarse"), orc.FieldSpec("fine")
+    P_c, P_f = orc.make_field_params(spec_c, 71, "sharp"), orc.make_field_params(spec_f, 72, "sharp")
+    target = torch.rand(36, 3, generator=torch.Generator().manual_seed(3))
+    epoch, S, I = 6, 32, 32
+
+    def rays_from(pose, device):
+        c2w = pose(cam.to(device))
+        o, d = get_rays(dirs.to(device), c2w)
+        nf = torch.tensor([2.0, 6.0], device=device).expand(36, 2)
+        return torch.cat([o, d, nf], 1)
+
+    # oracle
+    pose_o = LearnPose(2, True, True, init_c2w=init)
+    with torch.no_grad():
+        pose_o.r.add_(torch.tensor([[0.02, -0.01, 0.03], [-0.02, 0.01, 0.0]]))
+        pose_o.t.add_(torch.tensor([[0.01, 0.0, -0.02], [0.0, 0.02, 0.01]]))
+    res = orc.render_rays(spec_c, P_c, spec_f, P_f, rays_from(pose_o, "cpu"), n_samples=S, n_importance=I,
+                          noise_std=0.0, white_back=True, pe_w_xyz=orc.barf_weights(10, epoch),
+                          pe_w_dir=orc.barf_weights(4, epoch))
+    sum(orc.nerfw_loss(res, target).values()).backward()
+
+    # HIP
+    pose_h = LearnPose(2, True, True, init_c2w=init).to(dev)
+    pose_h.load_state_dict(pose_o.state_dict())
+    models = {"coarse": gpu_util.module_from(spec_c, P_c, True), "fine": gpu_util.module_from(spec_f, P_f, True)}
+    for m in models.values():
+        m.requires_grad_(False)                                                # only the poses are optimised here
+    emb = gpu_util.make_embeddings(10, True)
+    out = render_rays(models, emb, rays_from(pose_h, dev), torch.zeros(36, dtype=torch.long, device=dev), S, False, 0,
+                      0.0, I, 32768, True, False, current_epoch=epoch)
+    sum(orc.nerfw_loss(out, target.to(dev)).values()).backward()
+    for name in ("r", "t"):
+        g_h, g_o = getattr(pose_h, name).grad.cpu(), getattr(pose_o, name).grad
+        assert g_o.abs().max() > 0
+        assert (g_h - g_o).abs().max().item() <= GTOL * g_o.abs().max().item(), (name, g_h, g_o)
