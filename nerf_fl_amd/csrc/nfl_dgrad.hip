@@ -170,7 +170,7 @@ struct DgEpi {
 
 // NRT transposed row tiles (one per chunk) with up to three K segments
 template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NA, int NB, int NC, int NOUT, class Ring>
-NFL_DEV void dg_tiles(Ring& ring, int wave,
+NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
                       const b8 (&inA)[NA][1][2], int ksA, const b8 (&inB)[NB][1][2], int ksB,
                       const b8 (&inC)[NC][1][2], int ksC,
                       b8 (&out)[NOUT][1][2], int out_ks0, char* gst, int slot0) {
@@ -188,8 +188,8 @@ NFL_DEV void dg_tiles(Ring& ring, int wave,
         const char* wl = ring.template consume<(i >= 2) ? 2 : 0>();   // tile i-1 carried tile i-2's two stash stores
         dg_zero(acc[i & 1]);
         if (MASK) {      // the slot is recycled at the next consume(): take the mask now
-            mk[i & 1][0] = *reinterpret_cast<const b8*>(wl + WB + wave * 2048);
-            mk[i & 1][1] = *reinterpret_cast<const b8*>(wl + WB + wave * 2048 + 1024);
+            mk[i & 1][0] = *reinterpret_cast<const b8*>(wl + WB + wave_mask_off);
+            mk[i & 1][1] = *reinterpret_cast<const b8*>(wl + WB + wave_mask_off + 1024);
         }
         if constexpr (i > 0) {
             DgEpi<MASK, NOUT> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         const int i = (gg % SPR) * 32 + c;
         const bool ok = seg_ok && i < N;
         // padded segments (zero gradients) write to a scratch record past the end: no branch in the epilogue
-        char* gst = a.d_grad_stash + (size_t)(seg_ok ? ray0 * SPR + gg : A.n_seg_total) * NFL_GRD_SLOTS * 1024 + lane * 16;
+        char* gst = a.d_grad_stash + (size_t)(seg_ok ? ray0 * SPR + gg : A.n_seg_total) * NFL_GRD_SLOTS * 1024 + (2 * c + h) * 16;     // [sample][lane half][8] image, as the activation stash
 
         // geometry of this lane's sample, only for the gradient w.r.t. the rays
         float xraw[3] = {0.f, 0.f, 0.f}, xth[3] = {0.f, 0.f, 0.f}, xtl[3] = {0.f, 0.f, 0.f};
@@ -341,6 +341,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                 nfl_turns(draw[k], dth[k], dtl[k]);
             }
         }
+        // this wave's mask slice in a ring slot, at this lane's [sample][half] position of the stash image
+        const int moff = wave * 2048 + ((2 * c + h) - lane) * 16;
         float hg[9];
         {
             const float* hp = a.d_head_grads + ((size_t)ray * N + (i < N ? i : N - 1)) * 9;
@@ -370,13 +372,13 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         }
         b8 X[16][1][2], Y[16][1][2], Z[16][1][2];
         if (A.use_t) {
-            dg_tiles<WB, true, 4, 1, 1, 1>(ring, wave, dTs, 0, dTc, 0, dTb, 0, Y, 0, gst, NFL_GRD_G(4));
-            dg_tiles<WB, true, 4, 8, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(3));
-            dg_tiles<WB, true, 4, 8, 0, 0>(ring, wave, Y, 8, Y, 0, Y, 0, Y, 0, gst, NFL_GRD_G(2));
-            dg_tiles<WB, true, 4, 8, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(1));
+            dg_tiles<WB, true, 4, 1, 1, 1>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Y, 0, gst, NFL_GRD_G(4));
+            dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(3));
+            dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 8, Y, 0, Y, 0, Y, 0, gst, NFL_GRD_G(2));
+            dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(1));
             dg_latent_tile<8>(ring, Y, 8, (a.d_g_t_emb && seg_ok) ? a.d_g_t_emb + (size_t)ray * 16 : nullptr, 16, h, c);
         }
-        dg_tiles<WB, true, 4, 1, 0, 0>(ring, wave, dC, 0, dC, 0, dC, 0, X, 0, gst, NFL_GRD_DIRH);
+        dg_tiles<WB, true, 4, 1, 0, 0>(ring, moff, dC, 0, dC, 0, dC, 0, X, 0, gst, NFL_GRD_DIRH);
         if (A.has_a) {
             float* ga = (a.d_g_a_emb && seg_ok) ? a.d_g_a_emb + (size_t)ray * 48 : nullptr;
             dg_latent_tile<8>(ring, X, 0, ga, 32, h, c);
@@ -384,22 +386,22 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         }
         if (A.rays_tiles) dg_pe_tile<4, 0, 8>(ring, X, 0, h, draw, dth, dtl, pw_lds + 16, gd);
         if (A.use_t)
-            dg_tiles<WB, false, 8, 8, 8, 0>(ring, wave, X, 0, Y, 8, Y, 0, Z, 0, gst, NFL_GRD_FEAT);
+            dg_tiles<WB, false, 8, 8, 8, 0>(ring, moff, X, 0, Y, 8, Y, 0, Z, 0, gst, NFL_GRD_FEAT);
         else
-            dg_tiles<WB, false, 8, 8, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Z, 0, gst, NFL_GRD_FEAT);
-        dg_tiles<WB, true, 8, 16, 1, 0>(ring, wave, Z, 0, dS, 0, dS, 0, Y, 0, gst, NFL_GRD_D(8));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(7));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(6));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(5));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(4));
+            dg_tiles<WB, false, 8, 8, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Z, 0, gst, NFL_GRD_FEAT);
+        dg_tiles<WB, true, 8, 16, 1, 0>(ring, moff, Z, 0, dS, 0, dS, 0, Y, 0, gst, NFL_GRD_D(8));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(7));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(6));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(5));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(4));
         if (A.rays_tiles) {       // skip connection: delta_5 (still in X) reaches the encoded position too
             dg_pe_tile<NFX, 0, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
             dg_pe_tile<NFX, 1, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
             if (NKP > 4) dg_pe_tile<NFX, 2, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
         }
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(3));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(2));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, wave, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(1));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(3));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(2));
+        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(1));
         if (A.rays_tiles) {
             dg_pe_tile<NFX, 0, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
             dg_pe_tile<NFX, 1, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);

@@ -531,7 +531,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             const float z = nfl_z_at(a, ray, near, far, ii);
             const float zn = ii + 1 < N ? nfl_z_at(a, ray, near, far, ii + 1) : z;
             // padded segments recompute (and re-store) the last real one: identical bytes, no branch
-            st[cb] = STASH ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + lane * 16
+            // stash k-step image = [sample c][lane half h][8 values]: a sample's 16 features are 32 contiguous
+            // bytes, which makes the weight-gradient kernel's transposed LDS reads conflict-free
+            st[cb] = STASH ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + (2 * c + h) * 16
                            : nullptr;
             s_ray[cb] = ray;
             s_idx[cb] = ii;

@@ -76,11 +76,14 @@ __device__ __forceinline__ int wg_orig(int kind, int i) {
 
 // feature-on-lane MFMA operand of MFMA k-step m (samples 16m..16m+15) from a tile image (2 k-step pieces)
 __device__ __forceinline__ b8 wg_operand(const char* tile, int lane, int m) {
+    // stash k-step image: [sample c][lane half h][8 values] = 32 B per sample.  A 16-lane group reads 4
+    // samples x 16 features = 128 contiguous bytes; the two groups of a 32-lane half take the two k-steps of
+    // the tile (pieces WG_PSTRIDE apart, 32 B off the 1 KiB grid): every read is bank-conflict free.
     const int g = lane >> 4, ip = lane & 15, q = ip >> 2, p = ip & 3;
     const int c = 16 * m + 8 * (g >> 1) + q;
-    const char* ad = tile + (g & 1) * WG_PSTRIDE + (((p >> 1) * 32 + c) * 8 + 4 * (p & 1)) * 2;
+    const char* ad = tile + (g & 1) * WG_PSTRIDE + c * 32 + p * 8;
     const b4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad));
-    const b4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad + 4 * 8 * 2));
+    const b4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad + 4 * 32));
     b8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
