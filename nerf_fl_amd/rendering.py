@@ -60,9 +60,9 @@ def _f32c(t, name, shape=None):
         raise TypeError(f"`{name}` must be float32, got {t.dtype}")
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise ValueError(f"`{name}` has shape {tuple(t.shape)}, expected {tuple(shape)}")
-    t = t.detach()
-    if not t.is_contiguous() or t.data_ptr() % 16:
-        t = t.contiguous().clone() if t.data_ptr() % 16 else t.contiguous()
+    t = t.detach().contiguous()
+    if t.data_ptr() % 16:          # the kernels use 16-byte vector loads
+        t = t.clone()
     return t
 
 
@@ -467,6 +467,9 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         if needs_grad:
             if test_time:
                 raise RuntimeError("test_time=True is an inference mode; call it under torch.no_grad()")
+            if _precision != "f16x3":
+                raise RuntimeError("training needs the accurate mode: nerf_fl_amd.set_precision('f16x3') "
+                                   "(the fast 'f16' mode is inference-only)")
             outs = _RenderRaysFn.apply(cfg, rays_in if rays_grad else rays, a_emb, t_emb, *params)
             keys = [k for k in _result_keys(cfg)]
             return dict(zip(keys, outs))
