@@ -38,11 +38,11 @@ def all_reduce_gradients(params, group=None, average=True):
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     if average:
         flat.div_(world)
-    off = 0
+    views, off = [], 0
+    for g in grads:
+        views.append(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
     for p, g in zip(params, grads):
-        n = g.numel()
         if p.grad is None:
-            p.grad = flat[off:off + n].view_as(p).clone()
-        else:
-            p.grad.copy_(flat[off:off + n].view_as(p))
-        off += n
+            p.grad = g                      # the zeros created above; filled by the batched copy below
+    torch._foreach_copy_([p.grad for p in params], views)       # one multi-tensor kernel instead of ~50 copies
