@@ -144,12 +144,27 @@ typedef struct nfl_pass_args {
        computed by the caller exactly as barf_weight(freq, epoch) does; NULL = plain PosEmbedding     */
     const float* d_pe_w_xyz;    /* (n_emb_xyz) or NULL                                                   */
     const float* d_pe_w_dir;    /* (n_emb_dir) or NULL                                                   */
+    /* used by nfl_field_forward only (leave NULL / 0 otherwise) */
+    const float* d_embedded;
+    int32_t n_points, embedded_stride;
 } nfl_pass_args;
 
 /* Evaluate the field on every sample of every ray and alpha-composite on the
  * fly (one fused kernel; per-sample activations never reach HBM). */
 int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed,
                     const nfl_pass_args* args, void* stream);
+
+/* ---- the field alone (reference NeRF.forward, models/nerf.py:153-212) ---------
+ * d_x (n_points, row_stride) fp32 = [encoded xyz | encoded dir (+ appearance) | tau], exactly the
+ * matrix the reference module takes; d_out (n_points, 9) = [rgb(3), sigma, rgb_t(3), sigma_t, beta]
+ * (columns the mode does not compute are written as 0).  Same fused MFMA kernel as the
+ * renderer, with the encoding/compositing stages compiled out. */
+int nfl_field_forward(const void* h_plan, const void* d_plan, const void* d_packed,
+                      const float* d_x, int32_t n_points, int32_t row_stride,
+                      int32_t sigma_only, int32_t output_transient, float* d_out, void* stream);
+/* reference PosEmbedding / BarfPosEmbedding.forward (models/nerf.py:19-32, 61-77): d_x (n,3) ->
+ * d_out (n, 6*n_freqs+3); d_w (n_freqs) BARF weights or NULL */
+int nfl_posenc(const float* d_x, int32_t n, int32_t n_freqs, const float* d_w, float* d_out, void* stream);
 
 /* ---- backward (training) ---------------------------------------------------
  * The reference gets its gradients from autograd replaying ~100 ATen kernels per

@@ -55,6 +55,7 @@ class PassArgs(C.Structure):
         ("d_rgb_transient_only", C.c_void_p), ("d_depth_transient_only", C.c_void_p),
         ("d_field_raw", C.c_void_p), ("d_act_stash", C.c_void_p),
         ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p),
+        ("d_embedded", C.c_void_p), ("n_points", C.c_int32), ("embedded_stride", C.c_int32),
     ]
 
 
@@ -93,6 +94,9 @@ SYMBOLS = [
     ("nfl_render_pass", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassArgs), C.c_void_p]),
     ("nfl_sample_pdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("nfl_field_forward", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_void_p]),
+    ("nfl_posenc", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nfl_act_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
     ("nfl_grad_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
     ("nfl_bwd_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),

@@ -71,6 +71,31 @@ int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed
     return nfl_launch_render_x1(hp, d_plan, d_packed, a, stream);
 }
 
+int nfl_field_forward(const void* h_plan, const void* d_plan, const void* d_packed, const float* d_x,
+                      int32_t n_points, int32_t row_stride, int32_t sigma_only, int32_t output_transient,
+                      float* d_out, void* stream) {
+    const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
+    if (!hp || hp->magic != NFL_PLAN_MAGIC || hp->is_bwd || !d_plan || !d_packed || !d_x || !d_out) return NFL_EINVAL;
+    const int cx = 6 * hp->n_emb_xyz + 3;
+    const int need = sigma_only ? cx : cx + 27 + hp->n_a + ((output_transient && hp->has_t) ? hp->n_tau : 0);
+    if (n_points < 0 || row_stride < need) return NFL_EINVAL;
+    if (n_points == 0) return NFL_OK;
+    nfl_pass_args a;
+    memset(&a, 0, sizeof(a));
+    a.d_embedded = d_x;
+    a.n_points = n_points;
+    a.embedded_stride = row_stride;
+    a.n_rays = (n_points + 31) / 32;
+    a.n_samples = 32;
+    a.sigma_only = sigma_only ? 1 : 0;
+    a.d_t_emb = (output_transient && hp->has_t && !sigma_only) ? d_x : nullptr;     // flag only
+    a.d_a_emb = d_x;                                                                  // flag only
+    a.d_rays = d_x;
+    a.d_field_raw = d_out;
+    if (hp->prec == NFL_PREC_F16X3) return nfl_launch_render_x3(hp, d_plan, d_packed, &a, stream);
+    return nfl_launch_render_x1(hp, d_plan, d_packed, &a, stream);
+}
+
 int nfl_abi_version(void) { return NFL_ABI_VERSION; }
 
 const char* nfl_version(void) { return "nerf_fl_amd 0.1 (gfx950, HIP; abi 1)"; }
@@ -87,8 +112,8 @@ const char* nfl_strerror(int code) {
 }
 
 const char* nfl_render_kernel_name(int prec, int n_emb_xyz) {
-    if (prec == NFL_PREC_F16X3) return n_emb_xyz == 15 ? "nfl_render_kernel<3, 1, 15, false>" : "nfl_render_kernel<3, 1, 10, false>";
-    return n_emb_xyz == 15 ? "nfl_render_kernel<1, 1, 15, false>" : "nfl_render_kernel<1, 1, 10, false>";
+    if (prec == NFL_PREC_F16X3) return n_emb_xyz == 15 ? "nfl_render_kernel<3, 1, 15, 0>" : "nfl_render_kernel<3, 1, 10, 0>";
+    return n_emb_xyz == 15 ? "nfl_render_kernel<1, 1, 15, 0>" : "nfl_render_kernel<1, 1, 10, 0>";
 }
 
 }  // extern "C"

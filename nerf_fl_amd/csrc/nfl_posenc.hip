@@ -1,0 +1,31 @@
+// nfl_posenc.hip -- standalone positional encoding (reference PosEmbedding / BarfPosEmbedding.forward,
+// models/nerf.py:19-32, 61-77): (n,3) -> (n, 6N+3) = [x | w_k sin(2^k x) | w_k cos(2^k x) ...].
+// The renderer never calls this (it encodes in registers); it exists so that code which calls the
+// embedding module directly gets the same arithmetic (exact two-float x/2pi + minimax sine).  HBM-bound.
+#include "nfl_render_impl.h"
+
+__global__ __launch_bounds__(256) void nfl_posenc_kernel(const float* x, int n, int nf, const float* w, float* out) {
+    const int C = 6 * nf + 3;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)n * C) return;
+    const int b = (int)(idx / C), f = (int)(idx % C);
+    if (f < 3) {
+        out[idx] = x[(size_t)b * 3 + f];
+        return;
+    }
+    const int g = f - 3, k = g / 6, t = (g % 6) / 3, c = g % 3;
+    float th, tl;
+    nfl_turns(x[(size_t)b * 3 + c], th, tl);
+    const float sc = (float)(1 << k);
+    const float r = __builtin_amdgcn_fractf(th * sc) + tl * sc + (t ? 0.25f : 0.f);
+    out[idx] = (w ? w[k] : 1.f) * nfl_sin_rev(r);
+}
+
+extern "C" int nfl_posenc(const float* d_x, int32_t n, int32_t n_freqs, const float* d_w, float* d_out, void* stream) {
+    if (!d_x || !d_out || n < 0 || n_freqs < 1 || n_freqs > 16) return NFL_EINVAL;
+    if (n == 0) return NFL_OK;
+    const long long total = (long long)n * (6 * n_freqs + 3);
+    hipLaunchKernelGGL(nfl_posenc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), d_x, n, n_freqs, d_w, d_out);
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}

@@ -70,6 +70,7 @@ struct RenderArgs {
     int spr;                  // 32-sample segments per ray
     int rays_per_wg;
     float beta_min;
+    int n_points, emb_stride;   // NFL_MODE_EMBED: rows / row stride (floats) of a.d_embedded
 };
 
 // ---------------------------------------------------------------------------------
@@ -461,8 +462,13 @@ struct NflRenderCfg {
     static constexpr int LDS_BYTES = LDS_RING + LDS_BIAS + LDS_REC + LDS_CHK;
 };
 
-template <int NSPLIT, int NCB, int NFX, bool STASH>
+#define NFL_MODE_RENDER 0
+#define NFL_MODE_STASH 1      // render + bf16 activation stash for the backward
+#define NFL_MODE_EMBED 2      // NeRF.forward on already-encoded inputs (reference models/nerf.py:153-212): no
+                              // depth generation / encoding / compositing, 32 points per segment
+template <int NSPLIT, int NCB, int NFX, int MODE>
 __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) {
+    constexpr bool STASH = MODE == NFL_MODE_STASH, EMBED = MODE == NFL_MODE_EMBED;
     using C = NflRenderCfg<NSPLIT, NCB, NFX>;
     constexpr int NP = C::NP, NKP = C::NKP, NSLOT = C::NSLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -524,6 +530,29 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             const int i = (gg % SPR) * 32 + c;
             const bool ok = seg_ok && i < N;
             const int ii = i < N ? i : N - 1;
+            if constexpr (EMBED) {
+                // point b = 32 * segment + c of an (n_points, row) matrix [xyz enc | dir enc (+a) | tau]
+                const int b = ray * 32 + c;
+                const bool pok = seg_ok && b < A.n_points;
+                const float* xr = a.d_embedded + (size_t)(b < A.n_points ? b : A.n_points - 1) * A.emb_stride;
+                st[cb] = nullptr;
+                s_ray[cb] = ray;
+                s_idx[cb] = c;
+                s_ok[cb] = pok;
+                s_z[cb] = 0.f;
+                s_dl[cb] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < NKP; ++ks) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int f = 16 * ks + 8 * h + j;
+                        v[j] = f < 6 * NFX + 3 ? xr[f] : 0.f;
+                    }
+                    nfl_split8<NP>(v, P[ks][cb]);
+                }
+                continue;
+            }
             const float* rp = a.d_rays + (size_t)ray * 8;
             const f4v r0 = *reinterpret_cast<const f4v*>(rp);
             const f4v r1 = *reinterpret_cast<const f4v*>(rp + 4);
@@ -579,6 +608,23 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 h8 D[5][NCB][NP];
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
+                    if constexpr (EMBED) {
+                        const int b = s_ray[cb] * 32 + s_idx[cb];
+                        const float* xr = a.d_embedded + (size_t)(b < A.n_points ? b : A.n_points - 1) * A.emb_stride
+                                          + 6 * NFX + 3;
+#pragma unroll
+                        for (int ks = 0; ks < 5; ++ks) {
+                            if (ks >= 2 && !A.has_a) break;
+                            float v[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int f = 16 * (ks < 2 ? ks : ks - 2) + 8 * h + j;
+                                v[j] = ks < 2 ? (f < 27 ? xr[f] : 0.f) : xr[27 + f];
+                            }
+                            nfl_split8<NP>(v, D[ks][cb]);
+                        }
+                        continue;
+                    }
                     const float* dp = a.d_view_dir ? a.d_view_dir + (size_t)s_ray[cb] * 3
                                                    : a.d_rays + (size_t)s_ray[cb] * 8 + 3;
                     float raw[3], th[3], tl[3];
@@ -623,10 +669,20 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 h8 T[1][NCB][NP];
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
-                    const float* tp = a.d_t_emb + (size_t)s_ray[cb] * 16 + 8 * h;
-                    const f4v v0 = *reinterpret_cast<const f4v*>(tp);
-                    const f4v v1 = *reinterpret_cast<const f4v*>(tp + 4);
-                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    const int tb = s_ray[cb] * 32 + s_idx[cb];
+                    const float* tp = EMBED ? a.d_embedded + (size_t)(tb < A.n_points ? tb : A.n_points - 1) * A.emb_stride
+                                                  + 6 * NFX + 3 + 27 + (A.has_a ? 48 : 0) + 8 * h
+                                            : a.d_t_emb + (size_t)s_ray[cb] * 16 + 8 * h;
+                    float v[8];
+                    if constexpr (EMBED) {          // rows of the encoded matrix are not 16-byte aligned
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = tp[j];
+                    } else {
+                        const f4v v0 = *reinterpret_cast<const f4v*>(tp);
+                        const f4v v1 = *reinterpret_cast<const f4v*>(tp + 4);
+                        v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+                        v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+                    }
                     nfl_split8<NP>(v, T[0][cb]);
                     if (STASH) nfl_stash8(v, st[cb] + nfl_act_tau(NKP) * 1024);
                 }
@@ -671,6 +727,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 fr[0] = cr; fr[1] = cg; fr[2] = cbl; fr[3] = sg;
                 fr[4] = tr; fr[5] = tg; fr[6] = tb; fr[7] = sgt; fr[8] = bt;
             }
+            if constexpr (EMBED) continue;          // the field outputs are the result; nothing to composite
             float alpha, a_s = 0.f, a_t = 0.f;
             if (A.use_t) {
                 a_s = 1.f - expf(-dl * sg);
@@ -730,6 +787,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 for (int k = 0; k < NFL_NST; ++k) dst[k] = rec[k];
             }
         }
+        if constexpr (EMBED) continue;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -805,7 +863,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two prefetched chunks before exit
 }
 
-template <int NSPLIT, int NCB, int NFX, bool STASH>
+template <int NSPLIT, int NCB, int NFX, int MODE>
 static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void* d_packed,
                              const nfl_pass_args* args, hipStream_t stream) {
     using C = NflRenderCfg<NSPLIT, NCB, NFX>;
@@ -815,6 +873,12 @@ static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void
     A.a = *args;
     A.has_a = hp->has_a;
     A.use_t = (hp->has_t && args->d_t_emb != nullptr && !args->sigma_only) ? 1 : 0;
+    A.n_points = 0;
+    A.emb_stride = 0;
+    if (MODE == NFL_MODE_EMBED) {      // n_rays = segments of 32 points; d_t_emb != NULL only flags "transient head on"
+        A.n_points = args->n_points;
+        A.emb_stride = args->embedded_stride;
+    }
     A.n_chunks = args->sigma_only ? hp->n_chunks_sigma : (A.use_t ? hp->n_chunks : hp->n_chunks_static);
     A.n_rt = args->sigma_only ? hp->n_rt_sigma : (A.use_t ? hp->n_rt : hp->n_rt_static);
     A.bias_off = hp->bias_off;
@@ -834,21 +898,22 @@ static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void
     const int grid = (args->n_rays + rpw - 1) / rpw;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_render_kernel<NSPLIT, NCB, NFX, STASH>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_render_kernel<NSPLIT, NCB, NFX, MODE>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
             return NFL_ENODEV;
         attr_set = true;
     }
-    hipLaunchKernelGGL((nfl_render_kernel<NSPLIT, NCB, NFX, STASH>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
+    hipLaunchKernelGGL((nfl_render_kernel<NSPLIT, NCB, NFX, MODE>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }
 
 template <int NSPLIT, int NCB, int NFX>
 static int nfl_launch_render(const NflPlan* hp, const void* d_plan, const void* d_packed,
                              const nfl_pass_args* args, hipStream_t stream) {
+    if (args->d_embedded) return nfl_launch_render_t<NSPLIT, NCB, NFX, NFL_MODE_EMBED>(hp, d_plan, d_packed, args, stream);
     if (args->d_act_stash) {
         if (NSPLIT != 3) return NFL_EINVAL;        // the training stash is written by the accurate mode only
-        return nfl_launch_render_t<NSPLIT, NCB, NFX, (NSPLIT == 3)>(hp, d_plan, d_packed, args, stream);
+        return nfl_launch_render_t<NSPLIT, NCB, NFX, (NSPLIT == 3 ? NFL_MODE_STASH : NFL_MODE_RENDER)>(hp, d_plan, d_packed, args, stream);
     }
-    return nfl_launch_render_t<NSPLIT, NCB, NFX, false>(hp, d_plan, d_packed, args, stream);
+    return nfl_launch_render_t<NSPLIT, NCB, NFX, NFL_MODE_RENDER>(hp, d_plan, d_packed, args, stream);
 }

@@ -28,11 +28,8 @@ class PosEmbedding(nn.Module):
         self.freqs = 2 ** torch.linspace(0, max_logscale, N_freqs)   # attribute, not a buffer (as in the reference)
 
     def forward(self, x):
-        parts = [x]
-        for k in range(self.N_freqs):
-            y = x * float(2 ** k)
-            parts += [torch.sin(y), torch.cos(y)]
-        return torch.cat(parts, -1)
+        from . import rendering                 # HIP kernel nfl_posenc; device tensors only
+        return rendering.posenc(x, self.N_freqs)
 
 
 class BarfPosEmbedding(PosEmbedding):
@@ -64,11 +61,8 @@ class BarfPosEmbedding(PosEmbedding):
         return torch.tensor([self.barf_weight(f, epoch) for f in self.freqs], dtype=torch.float32)
 
     def forward(self, x, epoch):
-        parts = [x]
-        for k, w in enumerate(self.weights(epoch).tolist()):
-            y = x * float(2 ** k)
-            parts += [w * torch.sin(y), w * torch.cos(y)]
-        return torch.cat(parts, -1)
+        from . import rendering
+        return rendering.posenc(x, self.N_freqs, self.weights(epoch))
 
 
 class NeRF(nn.Module):
@@ -109,20 +103,7 @@ class NeRF(nn.Module):
             self.transient_beta = nn.Sequential(nn.Linear(W // 2, 1), nn.Softplus())
 
     def forward(self, x, sigma_only=False, output_transient=True):
-        cx, cda = self.in_channels_xyz, self.in_channels_dir + self.in_channels_a
-        xyz = x[:, :cx]
-        h = xyz
-        for i in range(self.D):
-            if i in self.skips:
-                h = torch.cat([xyz, h], 1)
-            h = getattr(self, f"xyz_encoding_{i + 1}")(h)
-        sigma = self.static_sigma(h)
-        if sigma_only:
-            return sigma
-        feat = self.xyz_encoding_final(h)
-        rgb = self.static_rgb(self.dir_encoding(torch.cat([feat, x[:, cx:cx + cda]], 1)))
-        out = [rgb, sigma]
-        if output_transient:
-            g = self.transient_encoding(torch.cat([feat, x[:, cx + cda:cx + cda + self.in_channels_t]], 1))
-            out += [self.transient_rgb(g), self.transient_sigma(g), self.transient_beta(g)]
-        return torch.cat(out, 1)
+        """(B, C) encoded inputs -> sigma | [rgb, sigma] | [rgb, sigma, rgb_t, sigma_t, beta]
+        (reference models/nerf.py:153-212), computed by the fused HIP field kernel."""
+        from . import rendering
+        return rendering.field_forward(self, x, sigma_only=sigma_only, output_transient=output_transient)

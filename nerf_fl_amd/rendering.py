@@ -171,6 +171,51 @@ def _field(model, n_emb_xyz, n_emb_dir, device):
     return f
 
 
+def field_forward(model, x, sigma_only=False, output_transient=True):
+    """NeRF.forward on an already-encoded (B, C) matrix (reference models/nerf.py:153-212) through the
+    fused HIP kernel.  Inference only: the result carries no autograd graph (training goes through
+    render_rays, whose backward is fused too)."""
+    if not x.is_cuda:
+        raise RuntimeError("nerf_fl_amd: NeRF.forward needs a ROCm device tensor (there is no CPU fallback)")
+    if x.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("nerf_fl_amd: NeRF.forward is inference-only; differentiate through render_rays")
+    if x.dim() != 2:
+        raise ValueError("x must be (B, C)")
+    n_xyz, n_dir = (model.in_channels_xyz - 3) // 6, (model.in_channels_dir - 3) // 6
+    f = _field(model, n_xyz, n_dir, x.device)
+    use_t = bool(output_transient) and not sigma_only
+    if use_t and not model.encode_transient:
+        raise ValueError("output_transient=True needs a model built with encode_transient")
+    x = x.detach().to(torch.float32).contiguous()
+    B = x.shape[0]
+    raw = torch.empty(B, 9, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().nfl_field_forward(f.h_plan, _ptr(f.d_plan), _ptr(f.packed), _ptr(x) if B else None, B,
+                                            x.shape[1], int(bool(sigma_only)), int(use_t), _ptr(raw) if B else None,
+                                            _stream()) if B else 0, "nfl_field_forward")
+    if sigma_only:
+        return raw[:, 3:4].contiguous()
+    return raw if use_t else raw[:, :4].contiguous()
+
+
+def posenc(x, n_freqs, weights=None):
+    """PosEmbedding / BarfPosEmbedding.forward (reference models/nerf.py:19-32, 61-77) on the device."""
+    if not x.is_cuda:
+        raise RuntimeError("nerf_fl_amd: PosEmbedding.forward needs a ROCm device tensor (there is no CPU fallback)")
+    if x.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("nerf_fl_amd: PosEmbedding.forward is inference-only; differentiate through render_rays")
+    if x.shape[-1] != 3:
+        raise ValueError("x must be (..., 3)")
+    lead = x.shape[:-1]
+    xf = x.detach().to(torch.float32).reshape(-1, 3).contiguous()
+    n = xf.shape[0]
+    out = torch.empty(n, 6 * n_freqs + 3, dtype=torch.float32, device=x.device)
+    w = None if weights is None else weights.to(device=x.device, dtype=torch.float32).contiguous()
+    if n:
+        _lib.check(_lib.lib().nfl_posenc(_ptr(xf), n, n_freqs, _ptr(w) if w is not None else None, _ptr(out), _stream()),
+                   "nfl_posenc")
+    return out.reshape(*lead, 6 * n_freqs + 3)
+
+
 def _linspace(n, device):
     k = (n, str(device))
     if k not in _lin_cache:
