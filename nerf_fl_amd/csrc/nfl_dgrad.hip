@@ -144,13 +144,11 @@ struct DgEpi {
             x0 = (float)mk[s][j] > 0.f ? x0 : 0.f;
             x1 = (float)mk[s][j + 1] > 0.f ? x1 : 0.f;
         }
-        const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
-        out[ks + s][0][0][j] = h0;
-        out[ks + s][0][0][j + 1] = h1;
-        out[ks + s][0][1][j] = (__bf16)(x0 - (float)h0);
-        out[ks + s][0][1][j + 1] = (__bf16)(x1 - (float)h1);
-        tmp[j] = h0;
-        tmp[j + 1] = h1;
+        float l0, l1;
+        const unsigned hi = nfl_split_pair<__bf16>(x0, x1, l0, l1);
+        reinterpret_cast<unsigned(&)[4]>(out[ks + s][0][0])[j / 2] = hi;
+        reinterpret_cast<unsigned(&)[4]>(out[ks + s][0][1])[j / 2] = nfl_pack2<__bf16>(l0, l1);
+        reinterpret_cast<unsigned(&)[4]>(tmp)[j / 2] = hi;
         if (OP % 4 == 3) *reinterpret_cast<b8*>(gst + (slot + s) * 1024) = tmp;
     }
     template <int K, int NK>

@@ -118,14 +118,52 @@ NFL_DEV float nfl_pe_feature(int f, const float (&raw)[3], const float (&th)[3],
     return pw[k] * nfl_sin_rev(r);
 }
 
+// relu on the bit pattern: one v_max_i32, and unlike v_max_f32 / v_med3_f32 it needs no canonicalising
+// v_max_f32 x,x in front (negative floats are negative integers; -0 and negative NaNs become +0)
+NFL_DEV float nfl_relu(float x) {
+    int b = __builtin_bit_cast(int, x);
+    b = b > 0 ? b : 0;
+    return __builtin_bit_cast(float, b);
+}
+template <class E>
+NFL_DEV unsigned nfl_pack2(float a, float b) {      // v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32 (round to nearest even)
+    typedef E e2v __attribute__((ext_vector_type(2)));
+    e2v r;
+    r[0] = (E)a;
+    r[1] = (E)b;
+    return __builtin_bit_cast(unsigned, r);
+}
+// (x0, x1) -> packed 16-bit hi pair (returned) and the fp32 residuals x - float(hi): one pack + (fp16) two
+// v_fma_mix_f32 reading the 16-bit halves directly (exact: a single rounding of x - hi, as the subtraction
+// it replaces; no v_cvt_f32_f16 / v_pk_add_f32 + s_nop)
+template <class E>
+NFL_DEV unsigned nfl_split_pair(float x0, float x1, float& l0, float& l1) {
+    const unsigned hi = nfl_pack2<E>(x0, x1);
+    if constexpr (__is_same(E, _Float16)) {
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(x0));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(x1));
+    } else {
+        // bf16 -> f32 is a shift / a mask (gfx950 has no v_fma_mix_f32_bf16); the empty asm keeps the two
+        // subtractions scalar (v_pk_add_f32 beside MFMAs costs more than two v_sub_f32)
+        l0 = x0 - __builtin_bit_cast(float, hi << 16);
+        asm volatile("" : "+v"(l0));
+        l1 = x1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    }
+    return hi;
+}
+
 template <int NP, class V8>
 NFL_DEV void nfl_split8(const float (&v)[8], V8 (&dst)[NP]) {
     using E = typename nfl_elem<V8>::type;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const E hi = (E)v[j];
-        dst[0][j] = hi;
-        if (NP == 2) dst[1][j] = (E)(v[j] - (float)hi);
+    for (int j = 0; j < 8; j += 2) {
+        if constexpr (NP == 2) {
+            float l0, l1;
+            reinterpret_cast<unsigned(&)[4]>(dst[0])[j / 2] = nfl_split_pair<E>(v[j], v[j + 1], l0, l1);
+            reinterpret_cast<unsigned(&)[4]>(dst[NP - 1])[j / 2] = nfl_pack2<E>(l0, l1);
+        } else {
+            reinterpret_cast<unsigned(&)[4]>(dst[0])[j / 2] = nfl_pack2<E>(v[j], v[j + 1]);
+        }
     }
 }
 
@@ -186,6 +224,9 @@ struct NflRing {
     char* i_dst;
     int i_nbytes;
 
+#ifdef NFL_STAMPS
+    unsigned long long t_wait = 0, t_bar = 0;   // cycles in consume(): DMA wait / workgroup barrier
+#endif
     int n_off0, n_off1;   // table entries of chunk c_issue, fetched one step ahead (no LDS latency after the barrier)
 
     NFL_DEV void begin_issue() {
@@ -199,7 +240,11 @@ struct NflRing {
     }
     template <int P>
     NFL_DEV void piece() {
+#ifdef NFL_ABL_NODMA
+        if constexpr (false) {
+#else
         if constexpr (P < MAXP) {
+#endif
             // uniform byte offset (SALU min), one VALU add for the lane: SGPR base + 32-bit VGPR offset
             unsigned byte = (unsigned)(wave + 4 * P) * 1024u;
             const unsigned last = (unsigned)i_nbytes - 1024u;
@@ -229,9 +274,18 @@ struct NflRing {
     // besides the MAXP pieces of the next one -- without it the wait would also sit on those stores.
     template <int EXTRA = 0>
     NFL_DEV const char* consume() {
+#if defined(NFL_STAMPS) && NFL_STAMPS >= 2
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + EXTRA) : "memory");
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        t_wait += c1 - c0;
+        t_bar += __builtin_amdgcn_s_memtime() - c1;
+#else
         // all but the MAXP (+EXTRA) youngest VMEM ops (= the younger chunk's pieces) are done
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + EXTRA) : "memory");
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         begin_issue();
         const char* base = lds + s_read * SLOT_BYTES + (threadIdx.x & 63) * 16;
@@ -324,20 +378,23 @@ struct NflActEpi {
 
     template <int OP>
     NFL_DEV void pair() {                      // OP 0..7: elements 2*OP, 2*OP+1 of the 16 accumulators
+#ifdef NFL_ABL_NOEPI
+        if (OP != 0) return;
+#endif
         constexpr int s = OP / 4, j = 2 * (OP % 4);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
-            if (RELU) {      // v_med3_f32: one instruction, no canonicalising v_max in front
-                x0 = __builtin_amdgcn_fmed3f(x0, 0.f, __builtin_inff());
-                x1 = __builtin_amdgcn_fmed3f(x1, 0.f, __builtin_inff());
+            if (RELU) {
+                x0 = nfl_relu(x0);
+                x1 = nfl_relu(x1);
             }
-            const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-            out[ks + s][cb][0][j] = h0;
-            out[ks + s][cb][0][j + 1] = h1;
-            if (NP == 2) {
-                out[ks + s][cb][NP - 1][j] = (_Float16)(x0 - (float)h0);
-                out[ks + s][cb][NP - 1][j + 1] = (_Float16)(x1 - (float)h1);
+            if constexpr (NP == 2) {
+                float l0, l1;
+                reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = nfl_split_pair<_Float16>(x0, x1, l0, l1);
+                reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][NP - 1])[j / 2] = nfl_pack2<_Float16>(l0, l1);
+            } else {
+                reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = nfl_pack2<_Float16>(x0, x1);
             }
             if (STASH) {
                 tmp[cb][j] = (__bf16)x0;
@@ -453,7 +510,11 @@ struct NflRenderCfg {
     static constexpr int KSB = 1024 * NP;
     static constexpr int MAXKS = 16 + (NKP > 5 ? NKP : 5);
     static constexpr int SLOT = MAXKS * KSB;
+#ifdef NFL_ABL_MAXP
+    static constexpr int MAXP = NFL_ABL_MAXP;        // ablation only: chunks longer than 4 KiB * MAXP are truncated
+#else
     static constexpr int MAXP = (SLOT + 4095) / 4096;
+#endif
     static constexpr int NSLOT = 4 * NCB;
     static constexpr int LDS_RING = 3 * SLOT;
     static constexpr int LDS_BIAS = NFL_MAX_RT * 32 * 4;
@@ -461,6 +522,21 @@ struct NflRenderCfg {
     static constexpr int LDS_CHK = (NFL_MAX_CHUNKS + 8 + 32) * 4;     // chunk offsets + 32 positional-encoding weights
     static constexpr int LDS_BYTES = LDS_RING + LDS_BIAS + LDS_REC + LDS_CHK;
 };
+
+// Diagnostic build only (make diag, -DNFL_STAMPS): per-phase s_memtime totals of every wave, written to a
+// buffer nothing else reads.  No stamp code exists in the product build.
+#ifdef NFL_STAMPS
+#define NFL_NSTAMP 20
+__device__ unsigned long long nfl_stamp_buf[1024 * 4 * NFL_NSTAMP];
+#define NFL_STAMP(i)                                                      \
+    do {                                                                  \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();    \
+        t_acc[i] += t_now - t_last;                                       \
+        t_last = t_now;                                                   \
+    } while (0)
+#else
+#define NFL_STAMP(i) do {} while (0)
+#endif
 
 #define NFL_MODE_RENDER 0
 #define NFL_MODE_STASH 1      // render + bf16 activation stash for the backward
@@ -513,6 +589,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
     ring.lane = lane;
     ring.prime();
 
+#ifdef NFL_STAMPS
+    unsigned long long t_acc[NFL_NSTAMP] = {};
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
     for (int tile = 0; tile < ntiles; ++tile) {
         // ------------------------------------------------------------ per-sample setup
         int s_ray[NCB], s_idx[NCB];
@@ -588,22 +668,33 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         // raw head outputs of sample c (lane half 0); extracted at once so the 16-register
         // accumulator tiles die immediately
         float o_sig[NCB], o_rgb[NCB][3], o_tr[NCB][5];
+        NFL_STAMP(0);
         nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1));       // L1
+        NFL_STAMP(1);
         nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2));        // L2
+        NFL_STAMP(2);
         nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3));        // L3
+        NFL_STAMP(3);
         nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4));        // L4
+        NFL_STAMP(4);
         nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5));      // L5 (skip)
+        NFL_STAMP(5);
         nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6));        // L6
+        NFL_STAMP(6);
         nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7));        // L7
+        NFL_STAMP(7);
         nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8));        // L8
+        NFL_STAMP(8);
         {
             f16v hacc[NCB];
             nfl_head<NP, NCB, 16>(ring, bias_lds, rt, h, Y, 0, hacc);                          // sigma
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) o_sig[cb] = hacc[cb][0];
         }
+        NFL_STAMP(9);
         if (!a.sigma_only) {
             nfl_dense<NP, NCB, 16, 0, false, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP));   // final (linear)
+            NFL_STAMP(10);
             {
                 h8 D[5][NCB][NP];
 #pragma unroll
@@ -650,11 +741,13 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         }
                     }
                 }
+                NFL_STAMP(11);
                 if (A.has_a)
                     nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
                 else
                     nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
             }
+            NFL_STAMP(12);
             {
                 f16v hacc[NCB];
                 nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 0, hacc);
@@ -665,6 +758,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     o_rgb[cb][2] = hacc[cb][2];
                 }
             }
+            NFL_STAMP(13);
             if (A.use_t) {
                 h8 T[1][NCB][NP];
 #pragma unroll
@@ -700,6 +794,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             }
         }
 
+        NFL_STAMP(14);
         // ------------------------------------------------------------ compositing, phase 1
         // (reference models/rendering.py:141-226).  Lanes 0..31 of each half own sample c.
         float w_loc[NCB], sig_t[NCB];
@@ -788,9 +883,11 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             }
         }
         if constexpr (EMBED) continue;
+        NFL_STAMP(15);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        NFL_STAMP(16);
 
         // ------------------------------------------------------------ compositing, phase 2
         // fold the segments of each ray in order; lane k (< NFL_NST) carries record entry k
@@ -859,8 +956,16 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         }
         // the next tile's first consume() barrier orders these LDS reads/writes
         // against the next phase-1 record writes (>= 70 barriers away).
+        NFL_STAMP(17);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two prefetched chunks before exit
+#ifdef NFL_STAMPS
+    NFL_STAMP(18);
+    t_acc[14] = ring.t_wait;
+    t_acc[19] = ring.t_bar;
+    if (lane == 0 && blockIdx.x < 1024)
+        for (int i = 0; i < NFL_NSTAMP; ++i) nfl_stamp_buf[(blockIdx.x * 4 + wave) * NFL_NSTAMP + i] = t_acc[i];
+#endif
 }
 
 template <int NSPLIT, int NCB, int NFX, int MODE>
