@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NFL_ABI_VERSION 1
+#define NFL_ABI_VERSION 2
 
 enum {
     NFL_OK = 0,
@@ -170,12 +170,14 @@ int nfl_posenc(const float* d_x, int32_t n, int32_t n_freqs, const float* d_w, f
  * The reference gets its gradients from autograd replaying ~100 ATen kernels per
  * point chunk over saved (chunk,256) activations.  Here:
  *   forward (d_act_stash, d_field_raw set)  ->  nfl_composite_backward  ->  nfl_mlp_dgrad
- *   ->  nfl_mlp_wgrad.  All gradients are fp32; MLP products are bf16 MFMA with fp32
- *   accumulation (dgrad: split operands, 3 products; wgrad: single product summed over
- *   all samples). */
+ *   ->  nfl_mlp_wgrad.  All gradients are returned in fp32.  The MLP part of the backward is
+ *   mixed precision: fp16 MFMA with fp32 accumulation on activations stashed in fp16 and on
+ *   gradients multiplied by a per-pass power-of-two LOSS SCALE, chosen on the device from
+ *   max|head gradient| (d_gmax, written by nfl_composite_backward) so that fp16's range is
+ *   used whatever the loss magnitude; the scale is divided out before anything is returned. */
 size_t nfl_act_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples);
 size_t nfl_grad_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples);
-/* dgrad plan / packed stream (transposed weights, bf16 hi+lo); same calling pattern as
+/* dgrad plan / packed stream (transposed weights, fp16); same calling pattern as
  * nfl_plan_build / nfl_pack_field (pack with nfl_pack_field using these plans). */
 /* rays_grad != 0: the stream also carries the tiles needed for the gradient w.r.t. the rays
  * (learnable poses, reference models/poses.py + train.py:86-98). */
@@ -201,6 +203,7 @@ typedef struct nfl_compbwd_args {
     const float* g_rgb_static;      /* (R,3)  _rgb_fine_static                             */
     const float* g_rgb_transient;   /* (R,3)  _rgb_fine_transient                          */
     float* d_head_grads;            /* out (R*N,9): d/d pre-activation [rgb,sigma,rgb_t,sigma_t,beta] */
+    float* d_gmax;                  /* out (1): max |head gradient| of this pass (zeroed, then atomically maxed) */
 } nfl_compbwd_args;
 int nfl_composite_backward(const nfl_compbwd_args* args, void* stream);
 
@@ -219,12 +222,14 @@ typedef struct nfl_dgrad_args {
     const float* d_z;               /* (R,N) depths the forward pass used                  */
     const float* d_pe_w_xyz;        /* as given to the forward pass (NULL = ones)          */
     const float* d_pe_w_dir;
+    const float* d_gmax;            /* (1) from nfl_composite_backward: fixes the loss scale of this pass */
 } nfl_dgrad_args;
 int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
                   const nfl_dgrad_args* args, void* stream);
 
-/* fp32 gradient tensors in nn.Linear layout, ACCUMULATED into (zero them first);
- * entries may be NULL (layer absent / gradient not wanted). */
+/* fp32 gradient tensors in nn.Linear layout, WRITTEN by nfl_mlp_wgrad (it zeroes them, accumulates
+ * with atomics, then divides the loss scale out); entries may be NULL (layer absent / gradient
+ * not wanted). */
 typedef struct nfl_field_grads {
     float* weight[NFL_NUM_LAYERS];
     float* bias[NFL_NUM_LAYERS];
@@ -233,8 +238,9 @@ typedef struct nfl_field_grads {
  * transient on/off; the caller uploads it verbatim like the other plans). */
 size_t nfl_wgrad_plan_bytes(void);
 int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, void* h_plan, size_t bytes);
+/* d_gmax: the same (1) float the dgrad of this pass was given (the stashed gradients carry its loss scale) */
 int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
-                  int32_t n_rays, int32_t n_samples, const nfl_field_grads* grads, void* stream);
+                  const float* d_gmax, int32_t n_rays, int32_t n_samples, const nfl_field_grads* grads, void* stream);
 
 /* ---- hierarchical sampling (reference sample_pdf, rendering.py:7-46, plus the
  * concat + sort of rendering.py:267-272) -------------------------------------

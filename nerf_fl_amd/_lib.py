@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFL_LIB") or os.path.join(_HERE, "libnerf_fl_amd.so")
 
-NFL_ABI_VERSION = 1
+NFL_ABI_VERSION = 2
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
 NFL_NUM_LAYERS = 19
@@ -66,7 +66,7 @@ class CompBwdArgs(C.Structure):
         ("reserved", C.c_int32),
         ("g_weights", C.c_void_p), ("g_opacity", C.c_void_p), ("g_rgb", C.c_void_p), ("g_depth", C.c_void_p),
         ("g_transient_sigmas", C.c_void_p), ("g_beta", C.c_void_p), ("g_rgb_static", C.c_void_p),
-        ("g_rgb_transient", C.c_void_p), ("d_head_grads", C.c_void_p),
+        ("g_rgb_transient", C.c_void_p), ("d_head_grads", C.c_void_p), ("d_gmax", C.c_void_p),
     ]
 
 
@@ -76,7 +76,7 @@ class DgradArgs(C.Structure):
         ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("use_transient", C.c_int32), ("reserved", C.c_int32),
         ("d_g_a_emb", C.c_void_p), ("d_g_t_emb", C.c_void_p),
         ("d_g_rays", C.c_void_p), ("d_rays", C.c_void_p), ("d_z", C.c_void_p),
-        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p),
+        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p), ("d_gmax", C.c_void_p),
     ]
 
 
@@ -105,7 +105,7 @@ SYMBOLS = [
     ("nfl_mlp_dgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DgradArgs), C.c_void_p]),
     ("nfl_wgrad_plan_bytes", C.c_size_t, []),
     ("nfl_wgrad_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),
-    ("nfl_mlp_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+    ("nfl_mlp_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                 C.POINTER(FieldGrads), C.c_void_p]),
     ("nfl_abi_version", C.c_int, []),
     ("nfl_version", C.c_char_p, []),

@@ -14,7 +14,8 @@
 // wavefront sum scan; rays longer than 64 samples are walked in 64-sample blocks with
 // scalar carries (forward for T, backward for the suffix).
 //
-// HBM-bound: reads 36+8(+4) B, writes 36 B per sample.
+// HBM-bound: reads 36+8(+4) B, writes 36 B per sample.  Also leaves max|head gradient| of the pass in d_gmax:
+// the fp16 MLP backward (nfl_dgrad / nfl_wgrad) derives its power-of-two loss scale from it.
 #include <hip/hip_runtime.h>
 
 #include "../../include/nerf_fl_amd.h"
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass 2: suffix sums and head gradients, last block first
+    float gmax = 0.f;        // max |head gradient| seen by this lane (loss scale of the fp16 MLP backward)
     float suffix = 0.f;      // sum of H_j over all samples after the current block
     const int nblk = (N + 63) / 64;
     for (int b = nblk - 1; b >= 0; --b) {
@@ -147,14 +149,28 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
         if (ok) {
             float* o = a.d_head_grads + ((size_t)ray * N + i) * 9;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) o[k] = out[k];
+            for (int k = 0; k < 9; ++k) {
+                o[k] = out[k];
+                gmax = fmaxf(gmax, fabsf(out[k]));
+            }
         }
+    }
+    if (a.d_gmax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d));
+        // non-negative floats order like their bit patterns; NaN/Inf gradients end up as a huge scale exponent
+        // that nfl_loss_scale_from_bits clamps (the NaNs themselves propagate to the result as in the reference)
+        // almost every wave finds the maximum already at or above its own: look before the (serialising) atomic
+        if (lane == 0 && __float_as_uint(gmax) > __atomic_load_n(reinterpret_cast<unsigned*>(a.d_gmax), __ATOMIC_RELAXED))
+            atomicMax(reinterpret_cast<unsigned*>(a.d_gmax), __float_as_uint(gmax));
     }
 }
 
 extern "C" int nfl_composite_backward(const nfl_compbwd_args* a, void* stream) {
     if (!a || !a->d_field_raw || !a->d_z || !a->d_head_grads) return NFL_EINVAL;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NFL_CB_MAXN) return NFL_EINVAL;
+    if (a->d_gmax && hipMemsetAsync(a->d_gmax, 0, sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
+        return NFL_ELAUNCH;
     if (a->n_rays == 0) return NFL_OK;
     hipLaunchKernelGGL(nfl_compbwd_kernel, dim3((a->n_rays + 3) / 4), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *a);

@@ -5,11 +5,16 @@
 //   delta_{l-1} = (W_l^T delta_l) (.) [h_{l-1} > 0]
 // with the same register-resident transposed formulation as the forward kernel
 // (nfl_render_impl.h): delta^T[feature, sample] tiles are MFMA accumulators, converted
-// to bf16 hi+lo they are the B operand of the next product; W^T streams through the
-// LDS ring as pre-packed bf16 hi+lo fragments (3 products per algorithmic product).
+// to fp16 they are the B operand of the next product; W^T streams through the LDS ring
+// as pre-packed fp16 fragments.  Mixed precision with a LOSS SCALE: every gradient in
+// this kernel is multiplied by the power of two S = nfl_loss_scale_from_bits(*d_gmax)
+// (max |head gradient| -> [2^7, 2^8)), so that fp16's 5-bit exponent is spent around the
+// values that matter whatever the magnitude of the loss; everything that leaves the
+// kernel in fp32 (latent / ray gradients) is multiplied by 1/S, and the gradient stash
+// keeps the scaled fp16 values for the weight-gradient GEMMs, which divide by S at the end.
 // The relu masks come from the forward pass' activation stash: the 2 KiB a wave needs
 // per row tile are DMA'd into the ring slot beside the weights, so the kernel issues no
-// ordinary global load inside the layer loop.  Every delta_l is written (bf16, fragment
+// ordinary global load inside the layer loop.  Every delta_l is written (fp16, scaled, fragment
 // order) to the gradient stash for the weight-gradient GEMMs (nfl_wgrad.hip).  The
 // appearance / transient latent gradients are the extra rows of W_dir^T / W_t0^T,
 // reduced over the samples of the ray with wave shuffles and accumulated with fp32 atomics.
@@ -27,9 +32,9 @@ struct DgradArgs {
 
 template <int NFX>
 struct NflDgradCfg {
-    static constexpr int NP = 2, NCB = 1;
+    static constexpr int NP = 1, NCB = 1;
     static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
-    static constexpr int KSB = 2048;
+    static constexpr int KSB = 1024;
     static constexpr int MAXKS = 17;
     static constexpr int WBYTES = MAXKS * KSB;
     static constexpr int AUXB = 4 * 2048;
@@ -125,31 +130,30 @@ NFL_DEV void dg_zero(f16v (&acc)[1]) {
 }
 
 // epilogue of a dgrad tile, cut into 8 pair-ops: relu mask (sign of the stashed activation),
-// bf16 hi+lo split into the next operand set, bf16 copy into the gradient stash
+// fp16 into the next operand set and into the gradient stash
 template <bool MASK, int NOUT>
 struct DgEpi {
     const f16v (&acc)[1];
-    const b8 (&mk)[2];
-    b8 (&out)[NOUT][1][2];
+    const h8 (&mk)[2];
+    h8 (&out)[NOUT][1][1];
     const int ks;
     char* const gst;
     const int slot;
-    b8 tmp;
+    h8 tmp;
 
     template <int OP>
     NFL_DEV void pair() {
         constexpr int s = OP / 4, j = 2 * (OP % 4);
         float x0 = acc[0][8 * s + j], x1 = acc[0][8 * s + j + 1];
-        if (MASK) {
-            x0 = (float)mk[s][j] > 0.f ? x0 : 0.f;
-            x1 = (float)mk[s][j + 1] > 0.f ? x1 : 0.f;
+        if (MASK) {      // stashed activations are relu outputs (>= +0): the unit was active iff its bits are nonzero
+            const unsigned m = reinterpret_cast<const unsigned(&)[4]>(mk[s])[j / 2];
+            x0 = (m & 0xffffu) ? x0 : 0.f;
+            x1 = (m >> 16) ? x1 : 0.f;
         }
-        float l0, l1;
-        const unsigned hi = nfl_split_pair<__bf16>(x0, x1, l0, l1);
+        const unsigned hi = nfl_pack2<_Float16>(x0, x1);
         reinterpret_cast<unsigned(&)[4]>(out[ks + s][0][0])[j / 2] = hi;
-        reinterpret_cast<unsigned(&)[4]>(out[ks + s][0][1])[j / 2] = nfl_pack2<__bf16>(l0, l1);
         reinterpret_cast<unsigned(&)[4]>(tmp)[j / 2] = hi;
-        if (OP % 4 == 3) *reinterpret_cast<b8*>(gst + (slot + s) * 1024) = tmp;
+        if (OP % 4 == 3) *reinterpret_cast<h8*>(gst + (slot + s) * 1024) = tmp;
     }
     template <int K, int NK>
     NFL_DEV void step() {
@@ -169,13 +173,13 @@ struct DgEpi {
 // NRT transposed row tiles (one per chunk) with up to three K segments
 template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NA, int NB, int NC, int NOUT, class Ring>
 NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
-                      const b8 (&inA)[NA][1][2], int ksA, const b8 (&inB)[NB][1][2], int ksB,
-                      const b8 (&inC)[NC][1][2], int ksC,
-                      b8 (&out)[NOUT][1][2], int out_ks0, char* gst, int slot0) {
+                      const h8 (&inA)[NA][1][1], int ksA, const h8 (&inB)[NB][1][1], int ksB,
+                      const h8 (&inC)[NC][1][1], int ksC,
+                      h8 (&out)[NOUT][1][1], int out_ks0, char* gst, int slot0) {
     constexpr int NK = NKA + NKB + NKC;
     f16v acc[2][1];
-    b8 mk[2][2];
-    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const b8& {
+    h8 mk[2][2];
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
         constexpr int k = decltype(K)::value;
         if constexpr (k < NKA) return inA[ksA + k][0][part];
         else if constexpr (k < NKA + NKB) return inB[ksB + k - NKA][0][part];
@@ -186,15 +190,15 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         const char* wl = ring.template consume<(i >= 2) ? 2 : 0>();   // tile i-1 carried tile i-2's two stash stores
         dg_zero(acc[i & 1]);
         if (MASK) {      // the slot is recycled at the next consume(): take the mask now
-            mk[i & 1][0] = *reinterpret_cast<const b8*>(wl + WB + wave_mask_off);
-            mk[i & 1][1] = *reinterpret_cast<const b8*>(wl + WB + wave_mask_off + 1024);
+            mk[i & 1][0] = *reinterpret_cast<const h8*>(wl + WB + wave_mask_off);
+            mk[i & 1][1] = *reinterpret_cast<const h8*>(wl + WB + wave_mask_off + 1024);
         }
         if constexpr (i > 0) {
             DgEpi<MASK, NOUT> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
-            nfl_tile<2, 1, NK, 0, b8>(acc[i & 1], wl, 0, getb, epi, ring);
+            nfl_tile<1, 1, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
         } else {
             NflNoEpi epi;
-            nfl_tile<2, 1, NK, 0, b8>(acc[i & 1], wl, 0, getb, epi, ring);
+            nfl_tile<1, 1, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
         }
         ring.template pieces<NK, Ring::MAXP>();
     });
@@ -204,21 +208,22 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
 
 // one tile whose rows are latent inputs: sum over the 32 samples of the segment, add to the ray's gradient
 template <int NK, int NIN, class Ring>
-NFL_DEV void dg_latent_tile(Ring& ring, const b8 (&in)[NIN][1][2], int ks0, float* dst, int nvalid, int h, int c) {
+NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][1][1], int ks0, float* dst, int nvalid, int h, int c,
+                            float inv_scale) {
     const char* wl = ring.consume();
     f16v acc[1];
     dg_zero(acc);
-    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const b8& {
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
         return in[ks0 + decltype(K)::value][0][part];
     };
     NflNoEpi epi;
-    nfl_tile<2, 1, NK, 0, b8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile<1, 1, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const float s = nfl_sum32(acc[0][r]);
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (dst && c == 0 && row < nvalid) atomicAdd(dst + row, s);
+        if (dst && c == 0 && row < nvalid) atomicAdd(dst + row, s * inv_scale);
     }
 }
 
@@ -227,17 +232,17 @@ NFL_DEV void dg_latent_tile(Ring& ring, const b8 (&in)[NIN][1][2], int ks0, floa
 // into the gradient of the 3 encoded coordinates of this lane's sample (partial: the two lane halves
 // hold different rows and are summed by the caller).
 template <int N, int T, int NK, int NIN, class Ring>
-NFL_DEV void dg_pe_tile(Ring& ring, const b8 (&in)[NIN][1][2], int ks0, int h,
+NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][1][1], int ks0, int h,
                         const float (&raw)[3], const float (&th)[3], const float (&tl)[3], const float* pw,
                         float (&g)[3]) {
     const char* wl = ring.consume();
     f16v acc[1];
     dg_zero(acc);
-    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const b8& {
+    auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
         return in[ks0 + decltype(K)::value][0][part];
     };
     NflNoEpi epi;
-    nfl_tile<2, 1, NK, 0, b8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile<1, 1, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
     (void)raw;
 #pragma unroll
@@ -296,6 +301,11 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid < 20) ? a.d_pe_w_dir[tid - 16] : 1.f;
     __syncthreads();
 
+    // loss scale of this pass (uniform; see nfl_plan.h)
+    const float scale = nfl_loss_scale_from_bits(__builtin_amdgcn_readfirstlane(
+        a.d_gmax ? *reinterpret_cast<const unsigned*>(a.d_gmax) : 0u));
+    const float inv_scale = 1.0f / scale;
+
     NflRingAux<C::SLOT, C::WBYTES, C::MAXP> ring;
     ring.gsrc = A.packed;
     ring.chunk_off = chk_lds;
@@ -345,21 +355,21 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         {
             const float* hp = a.d_head_grads + ((size_t)ray * N + (i < N ? i : N - 1)) * 9;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) hg[k] = (ok && h == 0) ? hp[k] : 0.f;
+            for (int k = 0; k < 9; ++k) hg[k] = (ok && h == 0) ? hp[k] * scale : 0.f;
         }
         // head gradients as natural-order B operands (k = 8h + j)
-        b8 dS[1][1][2], dC[1][1][2], dTs[1][1][2], dTc[1][1][2], dTb[1][1][2];
+        h8 dS[1][1][1], dC[1][1][1], dTs[1][1][1], dTc[1][1][1], dTb[1][1][1];
         {
             const float vS[8] = {hg[3], 0, 0, 0, 0, 0, 0, 0};
             const float vC[8] = {hg[0], hg[1], hg[2], 0, 0, 0, 0, 0};
             const float vTs[8] = {hg[7], 0, 0, 0, 0, 0, 0, 0};
             const float vTc[8] = {hg[4], hg[5], hg[6], 0, 0, 0, 0, 0};
             const float vTb[8] = {hg[8], 0, 0, 0, 0, 0, 0, 0};
-            nfl_split8<2>(vS, dS[0][0]);
-            nfl_split8<2>(vC, dC[0][0]);
-            nfl_split8<2>(vTs, dTs[0][0]);
-            nfl_split8<2>(vTc, dTc[0][0]);
-            nfl_split8<2>(vTb, dTb[0][0]);
+            nfl_split8<1>(vS, dS[0][0]);
+            nfl_split8<1>(vC, dC[0][0]);
+            nfl_split8<1>(vTs, dTs[0][0]);
+            nfl_split8<1>(vTc, dTc[0][0]);
+            nfl_split8<1>(vTb, dTb[0][0]);
             {
                 nfl_stash8(vS, gst + (NFL_GRD_HEADS + 0) * 1024);
                 nfl_stash8(vC, gst + (NFL_GRD_HEADS + 1) * 1024);
@@ -368,19 +378,19 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                 nfl_stash8(vTb, gst + (NFL_GRD_HEADS + 4) * 1024);
             }
         }
-        b8 X[16][1][2], Y[16][1][2], Z[16][1][2];
+        h8 X[16][1][1], Y[16][1][1], Z[16][1][1];
         if (A.use_t) {
             dg_tiles<WB, true, 4, 1, 1, 1>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Y, 0, gst, NFL_GRD_G(4));
             dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(3));
             dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 8, Y, 0, Y, 0, Y, 0, gst, NFL_GRD_G(2));
             dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(1));
-            dg_latent_tile<8>(ring, Y, 8, (a.d_g_t_emb && seg_ok) ? a.d_g_t_emb + (size_t)ray * 16 : nullptr, 16, h, c);
+            dg_latent_tile<8>(ring, Y, 8, (a.d_g_t_emb && seg_ok) ? a.d_g_t_emb + (size_t)ray * 16 : nullptr, 16, h, c, inv_scale);
         }
         dg_tiles<WB, true, 4, 1, 0, 0>(ring, moff, dC, 0, dC, 0, dC, 0, X, 0, gst, NFL_GRD_DIRH);
         if (A.has_a) {
             float* ga = (a.d_g_a_emb && seg_ok) ? a.d_g_a_emb + (size_t)ray * 48 : nullptr;
-            dg_latent_tile<8>(ring, X, 0, ga, 32, h, c);
-            dg_latent_tile<8>(ring, X, 0, ga ? ga + 32 : nullptr, 16, h, c);
+            dg_latent_tile<8>(ring, X, 0, ga, 32, h, c, inv_scale);
+            dg_latent_tile<8>(ring, X, 0, ga ? ga + 32 : nullptr, 16, h, c, inv_scale);
         }
         if (A.rays_tiles) dg_pe_tile<4, 0, 8>(ring, X, 0, h, draw, dth, dtl, pw_lds + 16, gd);
         if (A.use_t)
@@ -410,8 +420,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                 for (int k = 0; k < 3; ++k) {
                     const float gxk = gx[k] + __shfl_xor(gx[k], 32);
                     const float gdk = gd[k] + __shfl_xor(gd[k], 32);
-                    const float so = nfl_sum32(gxk);
-                    const float sd = nfl_sum32(gxk * zs + gdk);
+                    const float so = nfl_sum32(gxk) * inv_scale;
+                    const float sd = nfl_sum32(gxk * zs + gdk) * inv_scale;
                     if (lane == 0 && seg_ok) {
                         atomicAdd(a.d_g_rays + (size_t)ray * 8 + k, so);
                         atomicAdd(a.d_g_rays + (size_t)ray * 8 + 3 + k, sd);
@@ -464,7 +474,7 @@ extern "C" int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, con
                              const nfl_dgrad_args* args, void* stream) {
     const NflPlan* hp = static_cast<const NflPlan*>(h_bwd_plan);
     if (!hp || hp->magic != NFL_PLAN_MAGIC || !hp->is_bwd || !d_bwd_plan || !d_bwd_packed || !args) return NFL_EINVAL;
-    if (!args->d_head_grads || !args->d_act_stash || !args->d_grad_stash) return NFL_EINVAL;
+    if (!args->d_head_grads || !args->d_act_stash || !args->d_grad_stash || !args->d_gmax) return NFL_EINVAL;
     if (args->n_rays < 0 || args->n_samples < 1) return NFL_EINVAL;
     if (args->n_rays == 0) return NFL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -109,13 +109,13 @@ static int check_desc(const nfl_field_desc* d) {
     return NFL_OK;
 }
 
-// The dgrad stream (bf16, hi+lo): one transposed row tile per chunk, in the order the
+// The dgrad stream (fp16): one transposed row tile per chunk, in the order the
 // backward kernel walks the network (heads first).  chunk_aux names the activation-stash
 // slot whose sign is the relu mask of that tile.
 extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
-    common_init(d, NFL_PREC_F16X3, p);
-    p->elem = 1;
+    common_init(d, NFL_PREC_F16, p);     // fp16, one product: gradients are loss-scaled (nfl_loss_scale_from_bits)
+    p->elem = 0;
     p->is_bwd = 1;
     const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
     const int W = NFL_W, H = NFL_W / 2, nkp = p->nkp;

@@ -86,7 +86,7 @@ struct NflPlan {
 #else
 #define NFL_HD inline
 #endif
-// ---- per-segment (32 samples) stash records, in k-steps of 1 KiB (64 lanes x 8 bf16) ----
+// ---- per-segment (32 samples) stash records, in k-steps of 1 KiB (64 lanes x 8 fp16) ----
 // forward activations (inputs of every layer), written by the training-mode forward:
 //   P | h1..h8 | feat | D (dir PE 2, appearance 3) | dirh | tau | g1..g4
 NFL_HD constexpr int nfl_act_h(int nkp, int l) { return nkp + 16 * (l - 1); }   // l = 1..8
@@ -104,6 +104,20 @@ NFL_HD constexpr int nfl_act_slots(int nkp) { return nkp + 190; }
 #define NFL_GRD_G(m) (152 + 8 * ((m) - 1))
 #define NFL_GRD_HEADS 184
 #define NFL_GRD_SLOTS 189
+
+// Loss scale of a backward pass: the power of two that brings max|head gradient| (bits of the fp32 the
+// compositing backward left in d_gmax) to [2^7, 2^8).  fp16 overflows at 65504, so intermediate gradients may
+// grow 256x over the largest head gradient; anything 2^-21 below it is still a normal fp16.  dgrad and
+// wgrad both derive the scale from the same word, so they agree bit for bit.
+NFL_HD float nfl_loss_scale_from_bits(unsigned bits) {
+    int e = (int)((bits >> 23) & 0xffu) - 127;        // floor(log2(gmax)) for normal values
+    if (bits == 0u || e < -100) return 1.0f;           // no gradient at all (or denormal): nothing to scale
+    if (e > 100) e = 100;
+    const unsigned sbits = (unsigned)(127 + 7 - e) << 23;
+    union { unsigned u; float f; } cvt;
+    cvt.u = sbits;
+    return cvt.f;
+}
 
 #ifdef __cplusplus
 extern "C" {

@@ -167,12 +167,12 @@ NFL_DEV void nfl_split8(const float (&v)[8], V8 (&dst)[NP]) {
     }
 }
 
-// 8 values -> bf16 -> this lane's 16 B of a stash k-step (dst already includes lane*16)
+// 8 values -> fp16 -> this lane's 16 B of a stash k-step (dst already includes lane*16)
 NFL_DEV void nfl_stash8(const float (&v)[8], char* dst) {
-    b8 t;
+    h8 t;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = (__bf16)v[j];
-    *reinterpret_cast<b8*>(dst) = t;
+    for (int j = 0; j < 8; j += 2) reinterpret_cast<unsigned(&)[4]>(t)[j / 2] = nfl_pack2<_Float16>(v[j], v[j + 1]);
+    *reinterpret_cast<h8*>(dst) = t;
 }
 
 // natural-order B operand of one k-step of a positional encoding: lane half h holds
@@ -365,7 +365,7 @@ struct NflNoEpi {
 #define NFL_EPI_EARLY 2      // pair-ops done before the first MFMA of the following tile
 
 // Epilogue of an accumulator tile -> the two k-steps (ks, ks+1) of the next layer's B operand
-// (and, in the training forward, the bf16 activation stash), cut into 8 pair-ops per column
+// (and, in the training forward, the fp16 activation stash), cut into 8 pair-ops per column
 // block so it can be spread over the k-steps of the following tile.
 template <int NP, int NCB, bool RELU, bool STASH, int NOUT>
 struct NflActEpi {
@@ -374,7 +374,7 @@ struct NflActEpi {
     const int ks;
     char* const (&stash)[NCB];
     const int slot;
-    b8 tmp[NCB];
+    h8 tmp[NCB];
 
     template <int OP>
     NFL_DEV void pair() {                      // OP 0..7: elements 2*OP, 2*OP+1 of the 16 accumulators
@@ -389,17 +389,18 @@ struct NflActEpi {
                 x0 = nfl_relu(x0);
                 x1 = nfl_relu(x1);
             }
+            unsigned hi;
             if constexpr (NP == 2) {
                 float l0, l1;
-                reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = nfl_split_pair<_Float16>(x0, x1, l0, l1);
+                hi = nfl_split_pair<_Float16>(x0, x1, l0, l1);
                 reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][NP - 1])[j / 2] = nfl_pack2<_Float16>(l0, l1);
             } else {
-                reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = nfl_pack2<_Float16>(x0, x1);
+                hi = nfl_pack2<_Float16>(x0, x1);
             }
-            if (STASH) {
-                tmp[cb][j] = (__bf16)x0;
-                tmp[cb][j + 1] = (__bf16)x1;
-                if (OP % 4 == 3) *reinterpret_cast<b8*>(stash[cb] + (slot + s) * 1024) = tmp[cb];
+            reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
+            if (STASH) {        // the fp16 hi operand IS the stashed activation
+                reinterpret_cast<unsigned(&)[4]>(tmp[cb])[j / 2] = hi;
+                if (OP % 4 == 3) *reinterpret_cast<h8*>(stash[cb] + (slot + s) * 1024) = tmp[cb];
             }
         }
     }
@@ -539,7 +540,7 @@ __device__ unsigned long long nfl_stamp_buf[1024 * 4 * NFL_NSTAMP];
 #endif
 
 #define NFL_MODE_RENDER 0
-#define NFL_MODE_STASH 1      // render + bf16 activation stash for the backward
+#define NFL_MODE_STASH 1      // render + fp16 activation stash for the backward
 #define NFL_MODE_EMBED 2      // NeRF.forward on already-encoded inputs (reference models/nerf.py:153-212): no
                               // depth generation / encoding / compositing, 32 points per segment
 template <int NSPLIT, int NCB, int NFX, int MODE>

@@ -1,10 +1,11 @@
-// nfl_wgrad.hip -- weight / bias gradients of the field MLP as streaming bf16 GEMMs.
+// nfl_wgrad.hip -- weight / bias gradients of the field MLP as streaming fp16 GEMMs.
 //
 //   dW_l[out, in] = sum over samples  delta_l[sample, out] * h_{l-1}[sample, in]
 //   db_l[out]     = sum over samples  delta_l[sample, out]
 // (what autograd's Linear backward does per point chunk in the reference, models/nerf.py
 // 153-212).  Both operands come from the stashes the forward / dgrad kernels wrote: per
-// 32-sample segment, per layer, MFMA-fragment-ordered bf16 with the SAMPLE on the lane.
+// 32-sample segment, per layer, MFMA-fragment-ordered fp16 with the SAMPLE on the lane (the
+// gradients carry the pass' power-of-two loss scale, divided out at the flush).
 // The contraction index here is the sample, so both operands have to be presented with
 // the FEATURE on the lane and 8 consecutive samples in registers: the 1 KiB k-step images
 // are DMA'd verbatim into LDS and read back with ds_read_b64_tr_b16 (hardware 4x16
@@ -22,8 +23,8 @@
 #include "../../include/nerf_fl_amd.h"
 #include "nfl_plan.h"
 
-typedef __bf16 b8 __attribute__((ext_vector_type(8)));
-typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
 #define WG_MAX_OT 8      // out tiles (32 features) per job
@@ -52,6 +53,7 @@ struct WgPlan {          // host-built once per (field, transient on/off); the c
     uint32_t magic;
     int32_t n_jobs;
     int32_t act_slots, grd_slots;
+    int32_t w_numel[NFL_NUM_LAYERS], b_numel[NFL_NUM_LAYERS];   // sizes of the gradient tensors (0: layer absent)
     int32_t cost[WG_MAX_JOBS];     // DMA pieces per wave per segment (4 / 5 / 8): the job's relative cost
     WgJob job[WG_MAX_JOBS];
 };
@@ -75,16 +77,17 @@ __device__ __forceinline__ int wg_orig(int kind, int i) {
 #define WG_SLOT (WG_TSTRIDE * (WG_MAX_OT + WG_MAX_IT))
 
 // feature-on-lane MFMA operand of MFMA k-step m (samples 16m..16m+15) from a tile image (2 k-step pieces)
-__device__ __forceinline__ b8 wg_operand(const char* tile, int lane, int m) {
+__device__ __forceinline__ h8 wg_operand(const char* tile, int lane, int m) {
     // stash k-step image: [sample c][lane half h][8 values] = 32 B per sample.  A 16-lane group reads 4
     // samples x 16 features = 128 contiguous bytes; the two groups of a 32-lane half take the two k-steps of
     // the tile (pieces WG_PSTRIDE apart, 32 B off the 1 KiB grid): every read is bank-conflict free.
     const int g = lane >> 4, ip = lane & 15, q = ip >> 2, p = ip & 3;
     const int c = 16 * m + 8 * (g >> 1) + q;
     const char* ad = tile + (g & 1) * WG_PSTRIDE + c * 32 + p * 8;
-    const b4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad));
-    const b4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) b4*)(ad + 4 * 32));
-    b8 r;
+    typedef __fp16 hf4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    const h4 lo = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hf4*)(ad)));
+    const h4 hi = __builtin_bit_cast(h4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) hf4*)(ad + 4 * 32)));
+    h8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
@@ -162,7 +165,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
         s_read = (s_read + 1) & 3;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-            b8 av[WG_NOT], bv[NITW];
+            h8 av[WG_NOT], bv[NITW];
 #pragma unroll
             for (int a = 0; a < WG_NOT; ++a) av[a] = wg_operand(base + my_ot[a] * WG_TSTRIDE, lane, m);
 #pragma unroll
@@ -178,12 +181,14 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
             for (int b = 0; b < NITW; ++b)
 #pragma unroll
                 for (int a = 0; a < WG_NOT; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[a], bv[b], acc[a][b], 0, 0, 0);
+                                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // flush: fp32 atomics into the nn.Linear-layout gradient tensors
+    // flush: fp32 atomics into the nn.Linear-layout gradient tensors (still carrying the loss scale: a VALU
+    // multiply here would pull every accumulator through the 256 arch VGPRs and spill inside the streaming
+    // loop; nfl_wgrad_scale_kernel divides the finished tensors instead)
     const int n = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int a = 0; a < WG_NOT; ++a) {
@@ -236,6 +241,20 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
         else if (nitw <= 6) wg_body<8, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
         else wg_body<8, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
     }
+}
+
+// Whole-tensor passes around the GEMM kernel: op 0 zeroes the gradient tensors, op 1 divides them by the loss
+// scale.  blockIdx.y = tensor (weights then biases), blockIdx.x strides over its elements.
+struct WgTensors {
+    float* ptr[2 * NFL_NUM_LAYERS];
+    int n[2 * NFL_NUM_LAYERS];
+};
+__global__ __launch_bounds__(256) void nfl_wgrad_scale_kernel(const WgTensors T, const int op, const float* gmax) {
+    float* p = T.ptr[blockIdx.y];
+    const int n = T.n[blockIdx.y];
+    if (p == nullptr || n == 0) return;
+    const float f = op == 0 ? 0.f : 1.0f / nfl_loss_scale_from_bits(*reinterpret_cast<const unsigned*>(gmax));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = op == 0 ? 0.f : p[i] * f;
 }
 
 // ---------------------------------------------------------------------------------
@@ -354,17 +373,24 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
         }
     }
     P.n_jobs = nj;
+    for (int L = 0; L < NFL_NUM_LAYERS; ++L) {
+        const bool tr = L >= NFL_P_T0;
+        const int rows = (L <= NFL_P_FINAL) ? W : (L == NFL_P_DIR || (L >= NFL_P_T0 && L < NFL_P_T0 + 4)) ? H
+                         : (L == NFL_P_RGB || L == NFL_P_TRGB) ? 3 : 1;
+        const bool present = tr ? p.has_t != 0 : true;      // transient layers of the model that this pass does not use get zero gradients
+        P.w_numel[L] = present ? rows * p.ld[L] : 0;
+        P.b_numel[L] = present ? rows : 0;
+    }
     return NFL_OK;
 }
 
 extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash,
-                             const char* d_grad_stash, int32_t n_rays, int32_t n_samples,
+                             const char* d_grad_stash, const float* d_gmax, int32_t n_rays, int32_t n_samples,
                              const nfl_field_grads* grads, void* stream) {
     const WgPlan* hp = static_cast<const WgPlan*>(h_wplan);
-    if (!hp || hp->magic != (NFL_PLAN_MAGIC ^ 0x57u) || !d_wplan || !d_act_stash || !d_grad_stash || !grads)
+    if (!hp || hp->magic != (NFL_PLAN_MAGIC ^ 0x57u) || !d_wplan || !d_act_stash || !d_grad_stash || !d_gmax || !grads)
         return NFL_EINVAL;
     if (n_rays < 0 || n_samples < 1) return NFL_EINVAL;
-    if (n_rays == 0) return NFL_OK;
     WgArgs A;
     memset(&A, 0, sizeof(A));
     A.plan = static_cast<const WgPlan*>(d_wplan);
@@ -395,6 +421,17 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
             return NFL_ENODEV;
         attr_set = true;
     }
-    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 4 * WG_SLOT, static_cast<hipStream_t>(stream), A);
+    WgTensors T;
+    for (int L = 0; L < NFL_NUM_LAYERS; ++L) {
+        T.ptr[L] = grads->weight[L];
+        T.n[L] = hp->w_numel[L];
+        T.ptr[NFL_NUM_LAYERS + L] = grads->bias[L];
+        T.n[NFL_NUM_LAYERS + L] = hp->b_numel[L];
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, 2 * NFL_NUM_LAYERS), dim3(256), 0, s, T, 0, d_gmax);
+    if (n_rays == 0) return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 4 * WG_SLOT, s, A);
+    hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, 2 * NFL_NUM_LAYERS), dim3(256), 0, s, T, 1, d_gmax);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

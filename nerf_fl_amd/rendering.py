@@ -361,6 +361,8 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     (ca.g_weights, ca.g_opacity, ca.g_rgb, ca.g_depth, ca.g_transient_sigmas, ca.g_beta, ca.g_rgb_static,
      ca.g_rgb_transient) = [_ptr(k) for k in keep]
     ca.d_head_grads = _ptr(head)
+    gmax = torch.empty(1, dtype=torch.float32, device=dev)      # loss scale source of this pass (zeroed by the call)
+    ca.d_gmax = _ptr(gmax)
     _lib.check(L.nfl_composite_backward(C.byref(ca), _stream()), "nfl_composite_backward")
 
     grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(field.desc), R, N), dtype=torch.uint8, device=dev)
@@ -372,7 +374,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     da = _lib.DgradArgs()
     da.d_head_grads, da.d_act_stash, da.d_grad_stash = _ptr(head), _ptr(st["act"]), _ptr(grad_stash)
     da.n_rays, da.n_samples, da.use_transient = R, N, int(use_t)
-    da.d_g_a_emb, da.d_g_t_emb = _ptr(g_a), _ptr(g_t)
+    da.d_g_a_emb, da.d_g_t_emb, da.d_gmax = _ptr(g_a), _ptr(g_t), _ptr(gmax)
     if g_rays is not None:
         da.d_g_rays, da.d_rays, da.d_z = _ptr(g_rays), _ptr(rays), _ptr(st["z"])
         da.d_pe_w_xyz, da.d_pe_w_dir = _ptr(cfg["pe_w_xyz"]), _ptr(cfg["pe_w_dir"])
@@ -380,7 +382,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     _lib.check(L.nfl_mlp_dgrad(bp["h"], _ptr(bp["d"]), _ptr(bp["packed"]), C.byref(da), _stream()), "nfl_mlp_dgrad")
 
     plist = field.param_list()
-    arena = torch.zeros(sum(w.numel() + b.numel() for _, w, b in plist), dtype=torch.float32, device=dev)
+    arena = torch.empty(sum(w.numel() + b.numel() for _, w, b in plist), dtype=torch.float32, device=dev)   # zeroed by the call
     fg = _lib.FieldGrads()
     views, off = [], 0
     for i, w, b in plist:
@@ -391,7 +393,8 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
         fg.weight[i], fg.bias[i] = gw.data_ptr(), gb.data_ptr()
         views += [gw, gb]
     h_wp, d_wp = field.wgrad_plan(use_t)
-    _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), R, N, C.byref(fg), _stream()),
+    _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), _ptr(gmax), R, N, C.byref(fg),
+                               _stream()),
                "nfl_mlp_wgrad")
     return views, g_a, g_t
 

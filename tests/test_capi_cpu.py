@@ -74,12 +74,12 @@ def test_bwd_plan_structure(L):
     buf = C.create_string_buffer(n)
     assert L.nfl_bwd_plan_build(C.byref(d), 0, buf, n) == 0
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
-    assert hdr[3] == 1 and hdr[4] == 1 and hdr[5] == 0     # bf16 fragments, dgrad stream, no rays-gradient tiles
+    assert hdr[1] == 1 and hdr[2] == 1 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == 0     # fp16 single-product fragments, dgrad stream, no rays-gradient tiles
     n_rt, n_chunks, total_ks = hdr[12], hdr[15], hdr[18]
     # one transposed row tile per chunk: transient 4+12+1, rgb^T 4, appearance rows 2, feat 8, h8 8, 7 trunk layers x 8
     assert n_rt == n_chunks == 17 + 4 + 2 + 8 + 8 + 56
     assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 16 + 8 * 17 + 56 * 16
-    assert L.nfl_bwd_packed_bytes(C.byref(d), 0) == total_ks * 2048 + n_rt * 128
+    assert L.nfl_bwd_packed_bytes(C.byref(d), 0) == total_ks * 1024 + n_rt * 128
     # with the gradient w.r.t. the rays: + direction rows (1 tile, 8 ks) + encoded-position rows of layers 5 and 1 (2 x 2 tiles, 16 ks)
     assert L.nfl_bwd_plan_build(C.byref(d), 1, buf, n) == 0
     hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)

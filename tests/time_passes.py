@@ -57,10 +57,13 @@ if prec == "f16x3":
     ca.noise_std, ca.n_rays, ca.n_samples, ca.use_transient, ca.white_back = 1.0, R, F, 0, 1
     ca.g_rgb = rnd._ptr(grads[2])
     ca.d_head_grads = rnd._ptr(head)
+    gmax = torch.zeros(1, device=dev)
+    ca.d_gmax = rnd._ptr(gmax)
     print("composite backward    %.3f ms" % timeit(lambda: _lib.check(L.nfl_composite_backward(C.byref(ca), rnd._stream()), "cb")))
     da = _lib.DgradArgs()
     da.d_head_grads, da.d_act_stash, da.d_grad_stash = rnd._ptr(head), rnd._ptr(st["act"]), rnd._ptr(grad_stash)
     da.n_rays, da.n_samples, da.use_transient = R, F, 0
+    da.d_gmax = rnd._ptr(gmax)
     print("dgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_dgrad(bp['h'], rnd._ptr(bp['d']), rnd._ptr(bp['packed']), C.byref(da), rnd._stream()), "dg")))
     plist = f.param_list()
     arena = torch.zeros(sum(w.numel() + b.numel() for _, w, b in plist), device=dev)
@@ -70,5 +73,5 @@ if prec == "f16x3":
         fg.weight[i] = arena[off:off + w.numel()].data_ptr(); off += w.numel()
         fg.bias[i] = arena[off:off + b.numel()].data_ptr(); off += b.numel()
     h_wp, d_wp = f.wgrad_plan(False)
-    print("wgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_wgrad(h_wp, rnd._ptr(d_wp), rnd._ptr(st["act"]), rnd._ptr(grad_stash), R, F, C.byref(fg), rnd._stream()), "wg")))
+    print("wgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_wgrad(h_wp, rnd._ptr(d_wp), rnd._ptr(st["act"]), rnd._ptr(grad_stash), rnd._ptr(gmax), R, F, C.byref(fg), rnd._stream()), "wg")))
     print("act stash %.2f GB, grad stash %.2f GB" % (st["act"].numel() / 1e9, grad_stash.numel() / 1e9))
