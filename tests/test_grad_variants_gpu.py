@@ -7,7 +7,7 @@ import torch
 from oracle import nerfw_oracle as orc
 
 pytestmark = pytest.mark.gpu
-GTOL = 2e-2
+GTOL = 1e-2
 
 CASES = {
     "ragged_24_40": dict(S=24, I=40, fine="base", white=True, perturb=1.0, noise_std=1.0, out_t=True),
