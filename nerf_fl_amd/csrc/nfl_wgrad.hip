@@ -150,19 +150,19 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     float bsum[WG_NOT] = {0.f, 0.f};
 
-    // 4-slot ring, three segments in flight
+    // 4-slot ring, all four slots in flight while the waves wait: a slot is refilled as soon as every wave has
+    // finished reading it (second barrier of the iteration), not one iteration later -- the kernel spends two
+    // thirds of its time waiting for HBM, so what counts is the number of bytes outstanding, not the barrier
     issue(seg0, 0);
     issue(seg0 + 1, 1);
     issue(seg0 + 2, 2);
-    int s_read = 0, s_issue = 3;
+    issue(seg0 + 3, 3);
+    int s_read = 0;
     for (int seg = seg0; seg < seg1; ++seg) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PW) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue(seg + 3, s_issue);
-        s_issue = (s_issue + 1) & 3;
         const char* base = smem + s_read * WG_SLOT;
-        s_read = (s_read + 1) & 3;
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             h8 av[WG_NOT], bv[NITW];
@@ -181,8 +181,14 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
             for (int b = 0; b < NITW; ++b)
 #pragma unroll
                 for (int a = 0; a < WG_NOT; ++a)
-                                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
+        // every operand of this segment is in registers: hand the slot back
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(seg + 4, s_read);
+        s_read = (s_read + 1) & 3;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
