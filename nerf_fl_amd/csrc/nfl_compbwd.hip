@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/nerf_fl_amd.h"
+#include "nfl_plan.h"
 
 #define NFL_CB_MAXN 1024
 
@@ -161,15 +162,16 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
         // non-negative floats order like their bit patterns; NaN/Inf gradients end up as a huge scale exponent
         // that nfl_loss_scale_from_bits clamps (the NaNs themselves propagate to the result as in the reference)
         // almost every wave finds the maximum already at or above its own: look before the (serialising) atomic
-        if (lane == 0 && __float_as_uint(gmax) > __atomic_load_n(reinterpret_cast<unsigned*>(a.d_gmax), __ATOMIC_RELAXED))
-            atomicMax(reinterpret_cast<unsigned*>(a.d_gmax), __float_as_uint(gmax));
+        unsigned* slot = reinterpret_cast<unsigned*>(a.d_gmax) + (blockIdx.x & (NFL_GMAX_SLOTS - 1));
+        if (lane == 0 && __float_as_uint(gmax) > __atomic_load_n(slot, __ATOMIC_RELAXED))
+            atomicMax(slot, __float_as_uint(gmax));
     }
 }
 
 extern "C" int nfl_composite_backward(const nfl_compbwd_args* a, void* stream) {
     if (!a || !a->d_field_raw || !a->d_z || !a->d_head_grads) return NFL_EINVAL;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NFL_CB_MAXN) return NFL_EINVAL;
-    if (a->d_gmax && hipMemsetAsync(a->d_gmax, 0, sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
+    if (a->d_gmax && hipMemsetAsync(a->d_gmax, 0, NFL_GMAX_SLOTS * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
         return NFL_ELAUNCH;
     if (a->n_rays == 0) return NFL_OK;
     hipLaunchKernelGGL(nfl_compbwd_kernel, dim3((a->n_rays + 3) / 4), dim3(256), 0,

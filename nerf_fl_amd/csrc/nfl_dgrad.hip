@@ -144,13 +144,17 @@ struct DgEpi {
     template <int OP>
     NFL_DEV void pair() {
         constexpr int s = OP / 4, j = 2 * (OP % 4);
-        float x0 = acc[0][8 * s + j], x1 = acc[0][8 * s + j + 1];
-        if (MASK) {      // stashed activations are relu outputs (>= +0): the unit was active iff its bits are nonzero
-            const unsigned m = reinterpret_cast<const unsigned(&)[4]>(mk[s])[j / 2];
-            x0 = (m & 0xffffu) ? x0 : 0.f;
-            x1 = (m >> 16) ? x1 : 0.f;
+        const float x0 = acc[0][8 * s + j], x1 = acc[0][8 * s + j + 1];
+        unsigned hi = nfl_pack2<_Float16>(x0, x1);
+        if (MASK) {
+            // stashed activations are relu outputs (>= +0): the unit was active iff its fp16 bits are nonzero.
+            // min(bits, 1) per half is that predicate as 0/1; an integer multiply of the gradient's bits by it
+            // masks exactly (v_pk_min_u16 + v_pk_mul_lo_u16 instead of extract/compare/select per value)
+            // (inline asm: LLVM rewrites the C form back into compares and selects)
+            unsigned on;
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(reinterpret_cast<const unsigned(&)[4]>(mk[s])[j / 2]), "s"(0x00010001u));
+            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(on));
         }
-        const unsigned hi = nfl_pack2<_Float16>(x0, x1);
         reinterpret_cast<unsigned(&)[4]>(out[ks + s][0][0])[j / 2] = hi;
         reinterpret_cast<unsigned(&)[4]>(tmp)[j / 2] = hi;
         if (OP % 4 == 3) *reinterpret_cast<h8*>(gst + (slot + s) * 1024) = tmp;
@@ -302,8 +306,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     __syncthreads();
 
     // loss scale of this pass (uniform; see nfl_plan.h)
-    const float scale = nfl_loss_scale_from_bits(__builtin_amdgcn_readfirstlane(
-        a.d_gmax ? *reinterpret_cast<const unsigned*>(a.d_gmax) : 0u));
+    const float scale = nfl_loss_scale_from_bits(nfl_gmax_bits(a.d_gmax));
     const float inv_scale = 1.0f / scale;
 
     NflRingAux<C::SLOT, C::WBYTES, C::MAXP> ring;

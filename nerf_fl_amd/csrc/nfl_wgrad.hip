@@ -259,7 +259,16 @@ __global__ __launch_bounds__(256) void nfl_wgrad_scale_kernel(const WgTensors T,
     float* p = T.ptr[blockIdx.y];
     const int n = T.n[blockIdx.y];
     if (p == nullptr || n == 0) return;
-    const float f = op == 0 ? 0.f : 1.0f / nfl_loss_scale_from_bits(*reinterpret_cast<const unsigned*>(gmax));
+    float f = 0.f;
+    if (op != 0) {
+        unsigned v = reinterpret_cast<const unsigned*>(gmax)[threadIdx.x & (NFL_GMAX_SLOTS - 1)];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned o = __shfl_xor(v, d);
+            v = o > v ? o : v;
+        }
+        f = 1.0f / nfl_loss_scale_from_bits(__builtin_amdgcn_readfirstlane(v));
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) p[i] = op == 0 ? 0.f : p[i] * f;
 }
 

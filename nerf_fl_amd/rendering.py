@@ -361,7 +361,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     (ca.g_weights, ca.g_opacity, ca.g_rgb, ca.g_depth, ca.g_transient_sigmas, ca.g_beta, ca.g_rgb_static,
      ca.g_rgb_transient) = [_ptr(k) for k in keep]
     ca.d_head_grads = _ptr(head)
-    gmax = torch.empty(1, dtype=torch.float32, device=dev)      # loss scale source of this pass (zeroed by the call)
+    gmax = torch.empty(_lib.NFL_GMAX_SLOTS, dtype=torch.float32, device=dev)   # loss scale source of this pass (zeroed by the call)
     ca.d_gmax = _ptr(gmax)
     _lib.check(L.nfl_composite_backward(C.byref(ca), _stream()), "nfl_composite_backward")
 
