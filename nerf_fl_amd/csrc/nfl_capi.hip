@@ -40,7 +40,8 @@ static size_t n_segments(int32_t n_rays, int32_t n_samples) {
 size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples) {
     if (!d || n_rays < 0 || n_samples < 1) return 0;
     const int nkp = (6 * d->n_emb_xyz + 3 + 15) / 16;
-    return n_segments(n_rays, n_samples) * nfl_act_slots(nkp) * 1024 + 4096;      // + tail pad for 2-k-step tile reads
+    // records + tail pad for 2-k-step tile reads, then the relu-mask words
+    return nfl_msk_offset(n_segments(n_rays, n_samples), nkp) + n_segments(n_rays, n_samples) * NFL_MSK_WORDS * 256;
 }
 size_t nfl_grad_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples) {
     if (!d || n_rays < 0 || n_samples < 1) return 0;

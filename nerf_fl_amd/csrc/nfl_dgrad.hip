@@ -12,13 +12,18 @@
 // values that matter whatever the magnitude of the loss; everything that leaves the
 // kernel in fp32 (latent / ray gradients) is multiplied by 1/S, and the gradient stash
 // keeps the scaled fp16 values for the weight-gradient GEMMs, which divide by S at the end.
-// The relu masks come from the forward pass' activation stash: the 2 KiB a wave needs
-// per row tile are DMA'd into the ring slot beside the weights, so the kernel issues no
-// ordinary global load inside the layer loop.  Every delta_l is written (fp16, scaled, fragment
+// The relu masks come from the forward pass' mask records (one 32-bit word per lane and row
+// tile, nfl_plan.h): the 256 B a wave needs per row tile and segment are DMA'd into the ring
+// slot beside the weights, so the kernel issues no ordinary global load inside the layer loop.  Every delta_l is written (fp16, scaled, fragment
 // order) to the gradient stash for the weight-gradient GEMMs (nfl_wgrad.hip).  The
 // appearance / transient latent gradients are the extra rows of W_dir^T / W_t0^T,
 // reduced over the samples of the ray with wave shuffles and accumulated with fp32 atomics.
 #include "nfl_render_impl.h"
+
+// Two 32-sample segments (column blocks) per wave: with single-product fp16 a row tile is only 16 MFMAs per
+// column block, so the per-tile fixed costs (barrier, weight DMA, LDS reads of the A fragments) are shared by
+// 64 samples; the register file holds it because the walk needs only TWO 16-k-step operand sets (P, Q below).
+#define DG_NCB 2
 
 struct DgradArgs {
     const NflPlan* plan;
@@ -32,38 +37,44 @@ struct DgradArgs {
 
 template <int NFX>
 struct NflDgradCfg {
-    static constexpr int NP = 1, NCB = 1;
+    static constexpr int NP = 1, NCB = DG_NCB;
     static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
     static constexpr int KSB = 1024;
     static constexpr int MAXKS = 17;
     static constexpr int WBYTES = MAXKS * KSB;
-    static constexpr int AUXB = 4 * 2048;
+    static constexpr int AUXB = 4 * NCB * 256;
     static constexpr int SLOT = WBYTES + AUXB;
     static constexpr int MAXP = (WBYTES + 4095) / 4096;
     static constexpr int LDS_TAB = (2 * (NFL_MAX_CHUNKS + 8) + 32) * 4;
     static constexpr int LDS_BYTES = LDS_TAB + 3 * SLOT;
 };
 
-// ring with the per-wave mask pieces: pieces 0..MAXPW-1 are weights, MAXPW and MAXPW+1 the 2 KiB
-// of this wave's activation-stash slice that carries the relu mask of the tile
-template <int SLOT_BYTES, int WBYTES, int MAXPW>
+// ring with the per-wave mask pieces: pieces 0..MAXPW-1 are weights, the next one per column block the 256 B
+// (one dword per lane) of that segment's relu-mask word for the tile
+template <int SLOT_BYTES, int WBYTES, int MAXPW, int NCB>
 struct NflRingAux {
-    static constexpr int MAXP = MAXPW + 2;
+    static constexpr int MAXP = MAXPW + NCB;
     const char* gsrc;
     const int* chunk_off;
     const int* chunk_aux;
     char* lds;
-    const char* aux_src;      // activation stash (wave-uniform base)
+    const char* aux_src;      // mask records (wave-uniform base)
     size_t seg_stride;        // bytes per segment record
     int n_chunks, c_start, c_issue, s_issue, s_read;
-    int seg_issue, seg_last;  // this wave's (clamped) global segment for the tile c_issue belongs to
+    int seg_issue, seg_last;  // this wave's first (clamped) global segment for the tile c_issue belongs to
     int wave, lane;
     const char* i_src;
-    const char* i_aux;
+    const char* i_aux[NCB];
     char* i_dst;
     int i_nbytes;
 
     int n_off0, n_off1, n_aux;    // table entries of chunk c_issue, fetched one step ahead
+    // software count of this wave's VMEM operations, and its value right after the last piece of each chunk in
+    // flight: consume() may leave everything younger than that piece outstanding (pieces of the next chunk AND
+    // the stash stores issued since -- an HBM write acknowledgement takes longer than a 16-MFMA row tile).
+    // Operations that are not counted (loads, atomics, ...) only make the wait stricter.
+    int ops, mk0, mk1;        // mk0 / mk1: the count after the last piece of the oldest / youngest chunk in flight
+    NFL_DEV void note(int n) { ops += n; }
 
     NFL_DEV void fetch_tables() {
         n_off0 = __builtin_amdgcn_readfirstlane(chunk_off[c_issue]);
@@ -75,10 +86,14 @@ struct NflRingAux {
         i_src = gsrc + n_off0;
         i_dst = lds + s_issue * SLOT_BYTES;
         const int slot = n_aux < 0 ? 0 : n_aux;
-        i_aux = aux_src + (size_t)seg_issue * seg_stride + slot * 1024;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int sg = seg_issue + cb < seg_last ? seg_issue + cb : seg_last;
+            i_aux[cb] = aux_src + (size_t)sg * seg_stride + slot * 256;
+        }
         if (c_issue + 1 == n_chunks) {
             c_issue = c_start;
-            seg_issue = seg_issue + 4 < seg_last ? seg_issue + 4 : seg_last;
+            seg_issue = seg_issue + 4 * NCB < seg_last ? seg_issue + 4 * NCB : seg_last;
         } else {
             c_issue = c_issue + 1;
         }
@@ -87,6 +102,13 @@ struct NflRingAux {
     }
     template <int P>
     NFL_DEV void piece() {
+#ifdef DG_ABL_NODMA
+        return;
+#endif
+        if constexpr (P < MAXP) {
+            ops += 1;
+            if (P == MAXP - 1) mk1 = ops;
+        }
         if constexpr (P < MAXPW) {
             unsigned byte = (unsigned)(wave + 4 * P) * 1024u;
             const unsigned last = (unsigned)i_nbytes - 1024u;
@@ -96,9 +118,10 @@ struct NflRingAux {
                 (const __attribute__((address_space(1))) void*)(i_src + vo),
                 (__attribute__((address_space(3))) void*)(i_dst + byte), 16, 0, 0);
         } else if constexpr (P < MAXP) {
+            constexpr int cb = P - MAXPW;
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(i_aux + (unsigned)((P - MAXPW) * 1024u + (threadIdx.x & 63) * 16u)),
-                (__attribute__((address_space(3))) void*)(i_dst + WBYTES + wave * 2048 + (P - MAXPW) * 1024), 16, 0, 0);
+                (const __attribute__((address_space(1))) void*)(i_aux[cb] + (unsigned)((threadIdx.x & 63) * 4u)),
+                (__attribute__((address_space(3))) void*)(i_dst + WBYTES + wave * (256 * NCB) + cb * 256), 4, 0, 0);
         }
     }
     template <int P0, int P1>
@@ -106,15 +129,41 @@ struct NflRingAux {
         nfl_static_for<P0, P1>([&](auto P) __attribute__((always_inline)) { piece<decltype(P)::value>(); });
     }
     NFL_DEV void prime() {
+        ops = 0;
         fetch_tables();
         begin_issue();
         pieces<0, MAXP>();
+        mk0 = mk1;
         begin_issue();
         pieces<0, MAXP>();
     }
-    template <int EXTRA = 0>
+#ifdef NFL_STAMPS
+    unsigned long long t_wait = 0, t_bar = 0, n_cons = 0;
+#endif
     NFL_DEV const char* consume() {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + EXTRA) : "memory");
+#ifdef NFL_STAMPS
+        const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
+        // everything up to the last piece of the oldest chunk is done; younger operations may stay in flight
+        const int young = ops - mk0;
+        mk0 = mk1;               // the chunk issued during the coming tile overwrites mk1 at its last piece
+        if (young >= MAXP + 16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 16) : "memory");
+        else if (young >= MAXP + 12) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 12) : "memory");
+        else if (young >= MAXP + 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 8) : "memory");
+        else if (young >= MAXP + 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 4) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP) : "memory");
+#ifdef NFL_STAMPS
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_barrier();
+        t_wait += c1 - c0;
+        t_bar += __builtin_amdgcn_s_memtime() - c1;
+        n_cons += 1;
+        asm volatile("" ::: "memory");
+        begin_issue();
+        const char* base_ = lds + s_read * SLOT_BYTES + (threadIdx.x & 63) * 16;
+        s_read = s_read == 2 ? 0 : s_read + 1;
+        return base_;
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         begin_issue();
@@ -124,40 +173,56 @@ struct NflRingAux {
     }
 };
 
-NFL_DEV void dg_zero(f16v (&acc)[1]) {
+template <int NCB>
+NFL_DEV void dg_zero(f16v (&acc)[NCB]) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
 }
 
 // epilogue of a dgrad tile, cut into 8 pair-ops: relu mask (sign of the stashed activation),
 // fp16 into the next operand set and into the gradient stash
-template <bool MASK, int NOUT>
+template <bool MASK, int NOUT, int NCB>
 struct DgEpi {
-    const f16v (&acc)[1];
-    const h8 (&mk)[2];
-    h8 (&out)[NOUT][1][1];
+    const f16v (&acc)[NCB];
+    const unsigned (&mk)[NCB];
+    h8 (&out)[NOUT][NCB][1];
     const int ks;
-    char* const gst;
+    char* const (&gst)[NCB];
     const int slot;
-    h8 tmp;
 
     template <int OP>
     NFL_DEV void pair() {
         constexpr int s = OP / 4, j = 2 * (OP % 4);
-        const float x0 = acc[0][8 * s + j], x1 = acc[0][8 * s + j + 1];
-        unsigned hi = nfl_pack2<_Float16>(x0, x1);
-        if (MASK) {
-            // stashed activations are relu outputs (>= +0): the unit was active iff its fp16 bits are nonzero.
-            // min(bits, 1) per half is that predicate as 0/1; an integer multiply of the gradient's bits by it
-            // masks exactly (v_pk_min_u16 + v_pk_mul_lo_u16 instead of extract/compare/select per value)
-            // (inline asm: LLVM rewrites the C form back into compares and selects)
-            unsigned on;
-            asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(reinterpret_cast<const unsigned(&)[4]>(mk[s])[j / 2]), "s"(0x00010001u));
-            asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(on));
+#ifdef DG_ABL_NOEPI
+        if (OP != 0) return;
+#endif
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
+            unsigned hi = nfl_pack2<_Float16>(x0, x1);
+            if (MASK) {
+                // the forward's mask word has the pair's two predicates at bits 2*OP and 16 + 2*OP: shifted down
+                // they are 0/1 per half, and an integer multiply of the gradient's fp16 bits by them masks exactly
+                // (inline asm: LLVM rewrites the C form into compares and selects)
+                const unsigned on = (mk[cb] >> (2 * OP)) & 0x00010001u;
+                asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(on));
+            }
+            reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
+            // both stash stores of the tile are issued at its last pair-op, i.e. after every DMA piece of the
+            // tile they ride in: the ring's counted vmcnt wait can then leave TWO tiles of stores outstanding
+            // (the HBM write acknowledgement takes longer than one 16-MFMA row tile)
+#ifdef DG_ABL_NOSTORE
+            if (false) {
+#else
+            if (OP == 7) {
+#endif
+                // streaming stores: the 2.6 GB of stash must not evict the weight stream from L2
+                __builtin_nontemporal_store(out[ks][cb][0], reinterpret_cast<h8*>(gst[cb] + slot * 1024));
+                __builtin_nontemporal_store(out[ks + 1][cb][0], reinterpret_cast<h8*>(gst[cb] + (slot + 1) * 1024));
+            }
         }
-        reinterpret_cast<unsigned(&)[4]>(out[ks + s][0][0])[j / 2] = hi;
-        reinterpret_cast<unsigned(&)[4]>(tmp)[j / 2] = hi;
-        if (OP % 4 == 3) *reinterpret_cast<h8*>(gst + (slot + s) * 1024) = tmp;
     }
     template <int K, int NK>
     NFL_DEV void step() {
@@ -175,111 +240,116 @@ struct DgEpi {
 };
 
 // NRT transposed row tiles (one per chunk) with up to three K segments
-template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NA, int NB, int NC, int NOUT, class Ring>
+template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int NA, int NB, int NC, int NOUT, class Ring>
 NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
-                      const h8 (&inA)[NA][1][1], int ksA, const h8 (&inB)[NB][1][1], int ksB,
-                      const h8 (&inC)[NC][1][1], int ksC,
-                      h8 (&out)[NOUT][1][1], int out_ks0, char* gst, int slot0) {
+                      const h8 (&inA)[NA][NCB][1], int ksA, const h8 (&inB)[NB][NCB][1], int ksB,
+                      const h8 (&inC)[NC][NCB][1], int ksC,
+                      h8 (&out)[NOUT][NCB][1], int out_ks0, char* const (&gst)[NCB], int slot0) {
     constexpr int NK = NKA + NKB + NKC;
-    f16v acc[2][1];
-    h8 mk[2][2];
+    f16v acc[2][NCB];
+    unsigned mk[2][NCB];
     auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
         constexpr int k = decltype(K)::value;
-        if constexpr (k < NKA) return inA[ksA + k][0][part];
-        else if constexpr (k < NKA + NKB) return inB[ksB + k - NKA][0][part];
-        else return inC[ksC + k - NKA - NKB][0][part];
+        if constexpr (k < NKA) return inA[ksA + k][cb][part];
+        else if constexpr (k < NKA + NKB) return inB[ksB + k - NKA][cb][part];
+        else return inC[ksC + k - NKA - NKB][cb][part];
     };
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        const char* wl = ring.template consume<(i >= 2) ? 2 : 0>();   // tile i-1 carried tile i-2's two stash stores
-        dg_zero(acc[i & 1]);
-        if (MASK) {      // the slot is recycled at the next consume(): take the mask now
-            mk[i & 1][0] = *reinterpret_cast<const h8*>(wl + WB + wave_mask_off);
-            mk[i & 1][1] = *reinterpret_cast<const h8*>(wl + WB + wave_mask_off + 1024);
+        const char* wl = ring.consume();
+        dg_zero<NCB>(acc[i & 1]);
+        if (MASK) {      // the slot is recycled at the next consume(): take the masks now
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) mk[i & 1][cb] = *reinterpret_cast<const unsigned*>(wl + WB + wave_mask_off + cb * 256);
         }
         if constexpr (i > 0) {
-            DgEpi<MASK, NOUT> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
-            nfl_tile<1, 1, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
+            DgEpi<MASK, NOUT, NCB> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
+            nfl_tile<1, NCB, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
+            ring.note(2 * NCB);          // the epilogue's stash stores, issued at the tile's last k-step
         } else {
             NflNoEpi epi;
-            nfl_tile<1, 1, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
+            nfl_tile<1, NCB, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
         }
         ring.template pieces<NK, Ring::MAXP>();
     });
-    DgEpi<MASK, NOUT> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
+    DgEpi<MASK, NOUT, NCB> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
     last.all();
+    ring.note(2 * NCB);
 }
 
-// one tile whose rows are latent inputs: sum over the 32 samples of the segment, add to the ray's gradient
-template <int NK, int NIN, class Ring>
-NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][1][1], int ks0, float* dst, int nvalid, int h, int c,
+// one tile whose rows are latent inputs: sum over the 32 samples of each segment, add to its ray's gradient
+template <int NK, int NCB, int NIN, class Ring>
+NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, float* const (&dst)[NCB], int nvalid, int h, int c,
                             float inv_scale) {
     const char* wl = ring.consume();
-    f16v acc[1];
-    dg_zero(acc);
+    f16v acc[NCB];
+    dg_zero<NCB>(acc);
     auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
-        return in[ks0 + decltype(K)::value][0][part];
+        return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile<1, 1, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile<1, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float s = nfl_sum32(acc[0][r]);
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (dst && c == 0 && row < nvalid) atomicAdd(dst + row, s * inv_scale);
-    }
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s = nfl_sum32(acc[cb][r]);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (dst[cb] && c == 0 && row < nvalid) atomicAdd(dst[cb] + row, s * inv_scale);
+        }
 }
 
 // A transposed tile whose rows are positional-encoding features (tile T covers features 32T..32T+31 of
 // an N-frequency encoding): chain the feature gradients through d/dx [x, w_k sin(2^k x), w_k cos(2^k x)]
 // into the gradient of the 3 encoded coordinates of this lane's sample (partial: the two lane halves
 // hold different rows and are summed by the caller).
-template <int N, int T, int NK, int NIN, class Ring>
-NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][1][1], int ks0, int h,
-                        const float (&raw)[3], const float (&th)[3], const float (&tl)[3], const float* pw,
-                        float (&g)[3]) {
+template <int N, int T, int NK, int NCB, int NIN, class Ring>
+NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, int h,
+                        const float (&th)[NCB][3], const float (&tl)[NCB][3], const float* pw,
+                        float (&g)[NCB][3]) {
     const char* wl = ring.consume();
-    f16v acc[1];
-    dg_zero(acc);
+    f16v acc[NCB];
+    dg_zero<NCB>(acc);
     auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
-        return in[ks0 + decltype(K)::value][0][part];
+        return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile<1, 1, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile<1, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
-    (void)raw;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int f0 = 32 * T + (r & 3) + 8 * (r >> 2), f1 = f0 + 4;      // rows of lane half 0 / 1
-        constexpr int NF = 6 * N + 3;
-        if (f0 >= NF) continue;
-        // descriptor of a feature: coordinate, scale 2^k, phase of the DERIVATIVE in turns, weight index (-1: raw x)
-        const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3, c1 = f1 < 3 ? f1 : (f1 - 3) % 3;
-        const int k0 = f0 < 3 ? -1 : (f0 - 3) / 6, k1 = f1 < 3 ? -1 : (f1 - 3) / 6;
-        const int t0 = f0 < 3 ? 0 : ((f0 - 3) % 6) / 3, t1 = f1 < 3 ? 0 : ((f1 - 3) % 6) / 3;
-        const bool v1 = f1 < NF;
-        float coef0 = 1.f, coef1 = v1 ? 1.f : 0.f;
-        if (k0 >= 0) {
-            const float sc = (float)(1 << k0);
-            const float rr = __builtin_amdgcn_fractf(th[c0] * sc) + tl[c0] * sc + (t0 ? 0.5f : 0.25f);
-            coef0 = pw[k0] * sc * nfl_sin_rev(rr);                // d sin = cos ; d cos = -sin
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f0 = 32 * T + (r & 3) + 8 * (r >> 2), f1 = f0 + 4;      // rows of lane half 0 / 1
+            constexpr int NF = 6 * N + 3;
+            if (f0 >= NF) continue;
+            // descriptor of a feature: coordinate, scale 2^k, phase of the DERIVATIVE in turns, weight index (-1: raw x)
+            const int c0 = f0 < 3 ? f0 : (f0 - 3) % 3, c1 = f1 < 3 ? f1 : (f1 - 3) % 3;
+            const int k0 = f0 < 3 ? -1 : (f0 - 3) / 6, k1 = f1 < 3 ? -1 : (f1 - 3) / 6;
+            const int t0 = f0 < 3 ? 0 : ((f0 - 3) % 6) / 3, t1 = f1 < 3 ? 0 : ((f1 - 3) % 6) / 3;
+            const bool v1 = f1 < NF;
+            float coef0 = 1.f, coef1 = v1 ? 1.f : 0.f;
+            if (k0 >= 0) {
+                const float sc = (float)(1 << k0);
+                const float rr = __builtin_amdgcn_fractf(th[cb][c0] * sc) + tl[cb][c0] * sc + (t0 ? 0.5f : 0.25f);
+                coef0 = pw[k0] * sc * nfl_sin_rev(rr);                // d sin = cos ; d cos = -sin
+            }
+            if (v1 && k1 >= 0) {
+                const float sc = (float)(1 << k1);
+                const float rr = __builtin_amdgcn_fractf(th[cb][c1] * sc) + tl[cb][c1] * sc + (t1 ? 0.5f : 0.25f);
+                coef1 = pw[k1] * sc * nfl_sin_rev(rr);
+            }
+            const float a = acc[cb][r];
+            g[cb][c0] += h ? 0.f : a * coef0;
+            if (v1) g[cb][c1] += h ? a * coef1 : 0.f;
         }
-        if (v1 && k1 >= 0) {
-            const float sc = (float)(1 << k1);
-            const float rr = __builtin_amdgcn_fractf(th[c1] * sc) + tl[c1] * sc + (t1 ? 0.5f : 0.25f);
-            coef1 = pw[k1] * sc * nfl_sin_rev(rr);
-        }
-        const float a = acc[0][r];
-        g[c0] += h ? 0.f : a * coef0;
-        if (v1) g[c1] += h ? a * coef1 : 0.f;
-    }
 }
 
 template <int NFX>
 __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     using C = NflDgradCfg<NFX>;
-    constexpr int NKP = C::NKP, WB = C::WBYTES;
+    constexpr int NKP = C::NKP, WB = C::WBYTES, NCB = C::NCB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const chk_lds = reinterpret_cast<int*>(smem);
     int* const aux_lds = chk_lds + NFL_MAX_CHUNKS + 8;
@@ -294,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     if (ray1 > a.n_rays) ray1 = a.n_rays;
     if (ray0 >= ray1) return;
     const int seg_end = (ray1 - ray0) * SPR;
-    const int ntiles = (seg_end + 3) / 4;
+    const int ntiles = (seg_end + 4 * NCB - 1) / (4 * NCB);
 
     float* const pw_lds = reinterpret_cast<float*>(aux_lds + NFL_MAX_CHUNKS + 8);
     for (int i = tid; i <= A.n_chunks; i += 256) {
@@ -309,131 +379,160 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     const float scale = nfl_loss_scale_from_bits(nfl_gmax_bits(a.d_gmax));
     const float inv_scale = 1.0f / scale;
 
-    NflRingAux<C::SLOT, C::WBYTES, C::MAXP> ring;
+    NflRingAux<C::SLOT, C::WBYTES, C::MAXP, NCB> ring;
     ring.gsrc = A.packed;
     ring.chunk_off = chk_lds;
     ring.chunk_aux = aux_lds;
     ring.lds = smem + C::LDS_TAB;
-    ring.aux_src = a.d_act_stash;
-    ring.seg_stride = (size_t)nfl_act_slots(NKP) * 1024;
+    ring.aux_src = a.d_act_stash + nfl_msk_offset((size_t)A.n_seg_total, NKP);
+    ring.seg_stride = (size_t)NFL_MSK_WORDS * 256;
     ring.n_chunks = A.n_chunks;
     ring.c_start = A.c_start;
     ring.c_issue = A.c_start;
     ring.s_issue = 0;
     ring.s_read = 0;
     ring.seg_last = ray0 * SPR + seg_end - 1;
-    ring.seg_issue = ray0 * SPR + wave < ring.seg_last ? ray0 * SPR + wave : ring.seg_last;
+    ring.seg_issue = ray0 * SPR + wave * NCB < ring.seg_last ? ray0 * SPR + wave * NCB : ring.seg_last;
     ring.wave = wave;
     ring.lane = lane;
     ring.prime();
+#ifdef NFL_STAMPS
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int tile = 0; tile < ntiles; ++tile) {
-        const int g = tile * 4 + wave;
-        const bool seg_ok = g < seg_end;
-        const int gg = seg_ok ? g : seg_end - 1;
-        const int ray = ray0 + gg / SPR;
-        const int i = (gg % SPR) * 32 + c;
-        const bool ok = seg_ok && i < N;
-        // padded segments (zero gradients) write to a scratch record past the end: no branch in the epilogue
-        char* gst = a.d_grad_stash + (size_t)(seg_ok ? ray0 * SPR + gg : A.n_seg_total) * NFL_GRD_SLOTS * 1024 + (2 * c + h) * 16;     // [sample][lane half][8] image, as the activation stash
-
-        // geometry of this lane's sample, only for the gradient w.r.t. the rays
-        float xraw[3] = {0.f, 0.f, 0.f}, xth[3] = {0.f, 0.f, 0.f}, xtl[3] = {0.f, 0.f, 0.f};
-        float draw[3] = {0.f, 0.f, 0.f}, dth[3] = {0.f, 0.f, 0.f}, dtl[3] = {0.f, 0.f, 0.f};
-        float zs = 0.f, gx[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
-        if (A.rays_tiles && a.d_g_rays) {
-            const float* rp = a.d_rays + (size_t)ray * 8;
-            zs = a.d_z[(size_t)ray * N + (i < N ? i : N - 1)];
+        bool seg_ok[NCB];
+        int ray[NCB];
+        char* gst[NCB];
+        float hg[NCB][9];
+        // geometry of this lane's samples, only for the gradient w.r.t. the rays
+        float xth[NCB][3], xtl[NCB][3], dth[NCB][3], dtl[NCB][3], zs[NCB], gx[NCB][3], gd[NCB][3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                draw[k] = rp[3 + k];
-                xraw[k] = rp[k] + draw[k] * zs;
-                nfl_turns(xraw[k], xth[k], xtl[k]);
-                nfl_turns(draw[k], dth[k], dtl[k]);
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int g = tile * 4 * NCB + wave * NCB + cb;
+            seg_ok[cb] = g < seg_end;
+            const int gg = seg_ok[cb] ? g : seg_end - 1;
+            ray[cb] = ray0 + gg / SPR;
+            const int i = (gg % SPR) * 32 + c;
+            const bool ok = seg_ok[cb] && i < N;
+            // padded segments (zero gradients) write to a scratch record past the end: no branch in the epilogue
+            gst[cb] = a.d_grad_stash + (size_t)(seg_ok[cb] ? ray0 * SPR + gg : A.n_seg_total) * NFL_GRD_SLOTS * 1024 + (2 * c + h) * 16;     // [sample][lane half][8] image, as the activation stash
+            zs[cb] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xth[cb][k] = xtl[cb][k] = dth[cb][k] = dtl[cb][k] = gx[cb][k] = gd[cb][k] = 0.f;
+            if (A.rays_tiles && a.d_g_rays) {
+                const float* rp = a.d_rays + (size_t)ray[cb] * 8;
+                zs[cb] = a.d_z[(size_t)ray[cb] * N + (i < N ? i : N - 1)];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float dk = rp[3 + k];
+                    nfl_turns(rp[k] + dk * zs[cb], xth[cb][k], xtl[cb][k]);
+                    nfl_turns(dk, dth[cb][k], dtl[cb][k]);
+                }
             }
-        }
-        // this wave's mask slice in a ring slot, at this lane's [sample][half] position of the stash image
-        const int moff = wave * 2048 + ((2 * c + h) - lane) * 16;
-        float hg[9];
-        {
-            const float* hp = a.d_head_grads + ((size_t)ray * N + (i < N ? i : N - 1)) * 9;
+            const float* hp = a.d_head_grads + ((size_t)ray[cb] * N + (i < N ? i : N - 1)) * 9;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) hg[k] = (ok && h == 0) ? hp[k] * scale : 0.f;
+            for (int k = 0; k < 9; ++k) hg[cb][k] = (ok && h == 0) ? hp[k] * scale : 0.f;
         }
+        // this wave's mask words in a ring slot (wl carries lane * 16; the words are one dword per lane)
+        const int moff = wave * (256 * NCB) - lane * 12;
         // head gradients as natural-order B operands (k = 8h + j)
-        h8 dS[1][1][1], dC[1][1][1], dTs[1][1][1], dTc[1][1][1], dTb[1][1][1];
-        {
-            const float vS[8] = {hg[3], 0, 0, 0, 0, 0, 0, 0};
-            const float vC[8] = {hg[0], hg[1], hg[2], 0, 0, 0, 0, 0};
-            const float vTs[8] = {hg[7], 0, 0, 0, 0, 0, 0, 0};
-            const float vTc[8] = {hg[4], hg[5], hg[6], 0, 0, 0, 0, 0};
-            const float vTb[8] = {hg[8], 0, 0, 0, 0, 0, 0, 0};
-            nfl_split8<1>(vS, dS[0][0]);
-            nfl_split8<1>(vC, dC[0][0]);
-            nfl_split8<1>(vTs, dTs[0][0]);
-            nfl_split8<1>(vTc, dTc[0][0]);
-            nfl_split8<1>(vTb, dTb[0][0]);
-            {
-                nfl_stash8(vS, gst + (NFL_GRD_HEADS + 0) * 1024);
-                nfl_stash8(vC, gst + (NFL_GRD_HEADS + 1) * 1024);
-                nfl_stash8(vTs, gst + (NFL_GRD_HEADS + 2) * 1024);
-                nfl_stash8(vTc, gst + (NFL_GRD_HEADS + 3) * 1024);
-                nfl_stash8(vTb, gst + (NFL_GRD_HEADS + 4) * 1024);
-            }
+        h8 dS[1][NCB][1], dC[1][NCB][1], dTs[1][NCB][1], dTc[1][NCB][1], dTb[1][NCB][1];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const float vS[8] = {hg[cb][3], 0, 0, 0, 0, 0, 0, 0};
+            const float vC[8] = {hg[cb][0], hg[cb][1], hg[cb][2], 0, 0, 0, 0, 0};
+            const float vTs[8] = {hg[cb][7], 0, 0, 0, 0, 0, 0, 0};
+            const float vTc[8] = {hg[cb][4], hg[cb][5], hg[cb][6], 0, 0, 0, 0, 0};
+            const float vTb[8] = {hg[cb][8], 0, 0, 0, 0, 0, 0, 0};
+            nfl_split8<1>(vS, dS[0][cb]);
+            nfl_split8<1>(vC, dC[0][cb]);
+            nfl_split8<1>(vTs, dTs[0][cb]);
+            nfl_split8<1>(vTc, dTc[0][cb]);
+            nfl_split8<1>(vTb, dTb[0][cb]);
+            nfl_stash8(vS, gst[cb] + (NFL_GRD_HEADS + 0) * 1024);
+            nfl_stash8(vC, gst[cb] + (NFL_GRD_HEADS + 1) * 1024);
+            nfl_stash8(vTs, gst[cb] + (NFL_GRD_HEADS + 2) * 1024);
+            nfl_stash8(vTc, gst[cb] + (NFL_GRD_HEADS + 3) * 1024);
+            nfl_stash8(vTb, gst[cb] + (NFL_GRD_HEADS + 4) * 1024);
         }
-        h8 X[16][1][1], Y[16][1][1], Z[16][1][1];
+        // Two operand sets of 16 k-steps are enough for the whole walk: the transient chain ping-pongs between
+        // the halves of Q, d(dir hidden) lands in Q[0..8) next to dg1 in Q[8..16), d(feat) in P, then the trunk
+        // alternates Q, P, Q, ...
+        h8 P[16][NCB][1], Q[16][NCB][1];
         if (A.use_t) {
-            dg_tiles<WB, true, 4, 1, 1, 1>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Y, 0, gst, NFL_GRD_G(4));
-            dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(3));
-            dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 8, Y, 0, Y, 0, Y, 0, gst, NFL_GRD_G(2));
-            dg_tiles<WB, true, 4, 8, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, Y, 8, gst, NFL_GRD_G(1));
-            dg_latent_tile<8>(ring, Y, 8, (a.d_g_t_emb && seg_ok) ? a.d_g_t_emb + (size_t)ray * 16 : nullptr, 16, h, c, inv_scale);
+            dg_tiles<WB, true, 4, 1, 1, 1, NCB>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
+            float* gt[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) gt[cb] = (a.d_g_t_emb && seg_ok[cb]) ? a.d_g_t_emb + (size_t)ray[cb] * 16 : nullptr;
+            dg_latent_tile<8, NCB>(ring, Q, 8, gt, 16, h, c, inv_scale);
         }
-        dg_tiles<WB, true, 4, 1, 0, 0>(ring, moff, dC, 0, dC, 0, dC, 0, X, 0, gst, NFL_GRD_DIRH);
+        dg_tiles<WB, true, 4, 1, 0, 0, NCB>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
         if (A.has_a) {
-            float* ga = (a.d_g_a_emb && seg_ok) ? a.d_g_a_emb + (size_t)ray * 48 : nullptr;
-            dg_latent_tile<8>(ring, X, 0, ga, 32, h, c, inv_scale);
-            dg_latent_tile<8>(ring, X, 0, ga ? ga + 32 : nullptr, 16, h, c, inv_scale);
+            float* ga[NCB];
+            float* ga2[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                ga[cb] = (a.d_g_a_emb && seg_ok[cb]) ? a.d_g_a_emb + (size_t)ray[cb] * 48 : nullptr;
+                ga2[cb] = ga[cb] ? ga[cb] + 32 : nullptr;
+            }
+            dg_latent_tile<8, NCB>(ring, Q, 0, ga, 32, h, c, inv_scale);
+            dg_latent_tile<8, NCB>(ring, Q, 0, ga2, 16, h, c, inv_scale);
         }
-        if (A.rays_tiles) dg_pe_tile<4, 0, 8>(ring, X, 0, h, draw, dth, dtl, pw_lds + 16, gd);
+        if (A.rays_tiles) dg_pe_tile<4, 0, 8, NCB>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
         if (A.use_t)
-            dg_tiles<WB, false, 8, 8, 8, 0>(ring, moff, X, 0, Y, 8, Y, 0, Z, 0, gst, NFL_GRD_FEAT);
+            dg_tiles<WB, false, 8, 8, 8, 0, NCB>(ring, moff, Q, 0, Q, 8, Q, 0, P, 0, gst, NFL_GRD_FEAT);
         else
-            dg_tiles<WB, false, 8, 8, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Z, 0, gst, NFL_GRD_FEAT);
-        dg_tiles<WB, true, 8, 16, 1, 0>(ring, moff, Z, 0, dS, 0, dS, 0, Y, 0, gst, NFL_GRD_D(8));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(7));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(6));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(5));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(4));
-        if (A.rays_tiles) {       // skip connection: delta_5 (still in X) reaches the encoded position too
-            dg_pe_tile<NFX, 0, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+            dg_tiles<WB, false, 8, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_FEAT);
+        dg_tiles<WB, true, 8, 16, 1, 0, NCB>(ring, moff, P, 0, dS, 0, dS, 0, Q, 0, gst, NFL_GRD_D(8));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(7));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(6));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(5));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(4));
+        if (A.rays_tiles) {       // skip connection: delta_5 (still in P) reaches the encoded position too
+            dg_pe_tile<NFX, 0, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
         }
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(3));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, X, 0, X, 0, X, 0, Y, 0, gst, NFL_GRD_D(2));
-        dg_tiles<WB, true, 8, 16, 0, 0>(ring, moff, Y, 0, Y, 0, Y, 0, X, 0, gst, NFL_GRD_D(1));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(3));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(2));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(1));
         if (A.rays_tiles) {
-            dg_pe_tile<NFX, 0, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16>(ring, X, 0, h, xraw, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 0, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
             if (a.d_g_rays) {
                 // x = o + d z ; the view direction is d itself (no caller passes view_dir with learnable poses)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const float gxk = gx[k] + __shfl_xor(gx[k], 32);
-                    const float gdk = gd[k] + __shfl_xor(gd[k], 32);
-                    const float so = nfl_sum32(gxk) * inv_scale;
-                    const float sd = nfl_sum32(gxk * zs + gdk) * inv_scale;
-                    if (lane == 0 && seg_ok) {
-                        atomicAdd(a.d_g_rays + (size_t)ray * 8 + k, so);
-                        atomicAdd(a.d_g_rays + (size_t)ray * 8 + 3 + k, sd);
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float gxk = gx[cb][k] + __shfl_xor(gx[cb][k], 32);
+                        const float gdk = gd[cb][k] + __shfl_xor(gd[cb][k], 32);
+                        const float so = nfl_sum32(gxk) * inv_scale;
+                        const float sd = nfl_sum32(gxk * zs[cb] + gdk) * inv_scale;
+                        if (lane == 0 && seg_ok[cb]) {
+                            atomicAdd(a.d_g_rays + (size_t)ray[cb] * 8 + k, so);
+                            atomicAdd(a.d_g_rays + (size_t)ray[cb] * 8 + 3 + k, sd);
+                        }
                     }
-                }
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef NFL_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long* o = nfl_stamp_buf + (blockIdx.x * 4 + wave) * NFL_NSTAMP;
+        o[0] = __builtin_amdgcn_s_memtime() - t_begin;
+        o[1] = ring.t_wait;
+        o[2] = ring.t_bar;
+        o[3] = ring.n_cons;
+        o[4] = ntiles;
+    }
+#endif
 }
 
 template <int NFX>
@@ -457,7 +556,7 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int rpw = (args->n_rays + ncu - 1) / ncu;
-    const int rays_per_tile = 4 / A.spr;
+    const int rays_per_tile = 4 * DG_NCB / A.spr;
     if (rays_per_tile > 1) rpw = (rpw + rays_per_tile - 1) / rays_per_tile * rays_per_tile;
     if (rpw < 1) rpw = 1;
     A.rays_per_wg = rpw;

@@ -110,8 +110,8 @@ static int check_desc(const nfl_field_desc* d) {
 }
 
 // The dgrad stream (fp16): one transposed row tile per chunk, in the order the
-// backward kernel walks the network (heads first).  chunk_aux names the activation-stash
-// slot whose sign is the relu mask of that tile.
+// backward kernel walks the network (heads first).  chunk_aux names the mask word (nfl_msk_*)
+// that holds the relu mask of that tile.
 extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
     common_init(d, NFL_PREC_F16, p);     // fp16, one product: gradients are loss-scaled (nfl_loss_scale_from_bits)
@@ -122,19 +122,19 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
     Builder b{p};
     if (p->has_t) {
         for (int t = 0; t < 4; ++t)
-            b.ttile(32 * t, 32, nfl_act_g(nkp, 4) + 2 * t, [&](NflRowTile& r) {
+            b.ttile(32 * t, 32, nfl_msk_g(4) + t, [&](NflRowTile& r) {
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TSIGMA);
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_TRGB);
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TBETA);
             });
         for (int j = 3; j >= 1; --j)
             for (int t = 0; t < 4; ++t)
-                b.ttile(32 * t, 32, nfl_act_g(nkp, j) + 2 * t,
+                b.ttile(32 * t, 32, nfl_msk_g(j) + t,
                         [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0 + j); });
         b.ttile(W, d->n_tau, -1, [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0); });
     }
     for (int t = 0; t < 4; ++t)
-        b.ttile(32 * t, 32, nfl_act_dirh(nkp) + 2 * t,
+        b.ttile(32 * t, 32, nfl_msk_dirh() + t,
                 [&](NflRowTile& r) { Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_RGB); });
     if (p->has_a)
         for (int t = 0; t < 2; ++t)
@@ -148,14 +148,14 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
             if (p->has_t) Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0);
         });
     for (int t = 0; t < 8; ++t)
-        b.ttile(32 * t, 32, nfl_act_h(nkp, 8) + 2 * t, [&](NflRowTile& r) {
+        b.ttile(32 * t, 32, nfl_msk_h(8) + t, [&](NflRowTile& r) {
             Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_FINAL);
             Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_SIGMA);
         });
     const int npe = (cx + 31) / 32;         // 32-row tiles covering the encoded position
     for (int l = 8; l >= 2; --l) {          // layer l (1-based) transposed -> gradient of h_{l-1}
         for (int t = 0; t < 8; ++t)
-            b.ttile((l == 5 ? cx : 0) + 32 * t, 32, nfl_act_h(nkp, l - 1) + 2 * t,
+            b.ttile((l == 5 ? cx : 0) + 32 * t, 32, nfl_msk_h(l - 1) + t,
                     [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); });
         if (l == 5 && rays_grad)            // skip connection: rows that multiply the encoded position
             for (int t = 0; t < npe; ++t)

@@ -27,6 +27,7 @@
 // Chunks (the unit of the LDS ring; every chunk starts a new barrier epoch):
 //   L1: 2 row tiles per chunk; T2..T4: 2 row tiles per chunk; otherwise 1.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #define NFL_PLAN_MAGIC 0x4e464c31u /* "NFL1" */
@@ -96,6 +97,16 @@ NFL_HD constexpr int nfl_act_dirh(int nkp) { return nkp + 149; }
 NFL_HD constexpr int nfl_act_tau(int nkp) { return nkp + 157; }
 NFL_HD constexpr int nfl_act_g(int nkp, int m) { return nkp + 158 + 8 * (m - 1); }   // m = 1..4
 NFL_HD constexpr int nfl_act_slots(int nkp) { return nkp + 190; }
+// relu masks, written by the training-mode forward behind the activation records (one 32-bit word per lane and
+// row tile of a relu layer: bit 2p = value 2p of the lane's 16 accumulators was positive, bit 16+2p = value 2p+1;
+// 256 B per wave and tile instead of the 2 KiB of fp16 activations the dgrad kernel would otherwise re-read):
+//   h1..h8 (8 tiles each) | dirh (4) | g1..g4 (4 each)
+NFL_HD constexpr int nfl_msk_h(int l) { return 8 * (l - 1); }        // l = 1..8
+NFL_HD constexpr int nfl_msk_dirh() { return 64; }
+NFL_HD constexpr int nfl_msk_g(int m) { return 68 + 4 * (m - 1); }   // m = 1..4
+#define NFL_MSK_WORDS 84
+// byte offset of the mask records inside the activation stash buffer (after the records and their 4 KiB tail pad)
+NFL_HD constexpr size_t nfl_msk_offset(size_t n_seg, int nkp) { return n_seg * (size_t)nfl_act_slots(nkp) * 1024 + 4096; }
 // pre-activation gradients, written by the dgrad kernel:
 //   d1..d8 | dfeat | ddirh | dg1..dg4 | head grads as natural k-steps: dsigma, drgb, dsigma_t, drgb_t, dbeta
 #define NFL_GRD_D(l) (16 * ((l) - 1))

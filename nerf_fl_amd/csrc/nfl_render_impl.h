@@ -172,7 +172,7 @@ NFL_DEV void nfl_stash8(const float (&v)[8], char* dst) {
     h8 t;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) reinterpret_cast<unsigned(&)[4]>(t)[j / 2] = nfl_pack2<_Float16>(v[j], v[j + 1]);
-    *reinterpret_cast<h8*>(dst) = t;
+    __builtin_nontemporal_store(t, reinterpret_cast<h8*>(dst));
 }
 
 // natural-order B operand of one k-step of a positional encoding: lane half h holds
@@ -320,36 +320,64 @@ NFL_DEV void nfl_bias_init(f16v (&acc)[NCB], const float* bias_rt, int h) {
 // the barrier, with the matrix pipe idle).
 //   getb(K, cb, part) -> B operand of k-step K;  epi.template step<K, NK>() runs the epilogue
 //   work assigned to k-step K;  pieces P0+k are issued at k-step k.
-template <int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring>
+// The weight fragments are read with hand-issued ds_read_b128 and hand-counted s_waitcnt lgkmcnt(N): left to
+// hipcc, every third k-step got an `s_waitcnt lgkmcnt(0)` that also waits for the reads issued one instruction
+// earlier for k+2, so the full LDS latency was exposed once per three k-steps (1.4x the MFMA time with three
+// products per k-step, 2x with one).  LDS operations return in order, so "all but the N youngest" is exact: N =
+// the reads of k-step k+1.  Any LDS operation the compiler adds in between only makes the wait stricter.
+typedef unsigned nfl_u4 __attribute__((ext_vector_type(4)));
+template <int OFF>
+NFL_DEV nfl_u4 nfl_lds_read128(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field is 16 bits");
+    nfl_u4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// wait until at most N LDS operations are outstanding; the operands ride through so that their users stay below
+template <int N, int NP>
+NFL_DEV void nfl_lds_wait(nfl_u4 (&w)[NP]) {
+    if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
+    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[0]) : "n"(N));
+}
+
+// DEPTH = how many k-steps ahead the fragments are read (DEPTH + 1 register sets).  Two k-steps are 6 MFMAs with
+// three products per k-step but only 2 with one: the single-product kernels read 4 ahead, or every k-step waits
+// out most of the LDS latency (in-kernel stamps: 3.3 k cycles per 32-MFMA row tile with DEPTH 2).
+template <int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring, int DEPTH = (NP == 1 ? 4 : 2)>
 NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& getb, Epi&& epi, Ring& ring) {
     constexpr int KSB = 1024 * NP;
-    V8 w[3][NP];
+    constexpr int NW = DEPTH + 1;
+    (void)frag0;                          // == P0 (kept in the signature for the callers' readability)
+    nfl_u4 w[NW][NP];
+    const unsigned wa = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)wl;
     auto load = [&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
-        w[k % 3][0] = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB);
-        if (NP == 2) w[k % 3][NP - 1] = *reinterpret_cast<const V8*>(wl + (frag0 + k) * KSB + 1024);
+        w[k % NW][0] = nfl_lds_read128<(P0 + k) * KSB>(wa);
+        if constexpr (NP == 2) w[k % NW][NP - 1] = nfl_lds_read128<(P0 + k) * KSB + 1024>(wa);
     };
-    load(std::integral_constant<int, 0>{});
-    if constexpr (NK > 1) load(std::integral_constant<int, 1>{});
+    nfl_static_for<0, (DEPTH < NK ? DEPTH : NK)>([&](auto K) __attribute__((always_inline)) { load(K); });
     epi.early();                         // VALU work that hides the latency of the first LDS reads
     __builtin_amdgcn_sched_barrier(0);
     nfl_static_for<0, NK>([&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
+        // k-step k has landed; the reads of k+1 .. k+DEPTH-1 (already issued) may still be in flight
+        constexpr int younger = (NK - 1 - k) < (DEPTH - 1) ? (NK - 1 - k) : (DEPTH - 1);
+        nfl_lds_wait<younger * NP, NP>(w[k % NW]);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             if (NP == 2) {
-                acc[cb] = nfl_mfma(w[k % 3][NP - 1], getb(K, cb, 0), acc[cb]);
+                acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][NP - 1]), getb(K, cb, 0), acc[cb]);
                 if (cb == 0) {
-                    if constexpr (k + 2 < NK) load(std::integral_constant<int, k + 2>{});
+                    if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[cb] = nfl_mfma(w[k % 3][0], getb(K, cb, NP - 1), acc[cb]);
+                acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, NP - 1), acc[cb]);
                 if (cb == 0) ring.template piece<P0 + k>();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            acc[cb] = nfl_mfma(w[k % 3][0], getb(K, cb, 0), acc[cb]);
+            acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, 0), acc[cb]);
             if (NP == 1 && cb == 0) {
-                if constexpr (k + 2 < NK) load(std::integral_constant<int, k + 2>{});
+                if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
                 ring.template piece<P0 + k>();
             }
             if (cb == NCB - 1) epi.template step<k, NK>();
@@ -386,7 +414,10 @@ struct NflActEpi {
     const int ks;
     char* const (&stash)[NCB];
     const int slot;
+    char* const (&mstash)[NCB];      // relu-mask records of the lane's segments (training forward)
+    const int mword;                 // mask word of this tile
     h8 tmp[NCB];
+    unsigned m32[NCB];
 
     template <int OP>
     NFL_DEV void pair() {                      // OP 0..7: elements 2*OP, 2*OP+1 of the 16 accumulators
@@ -412,7 +443,13 @@ struct NflActEpi {
             reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
             if (STASH) {        // the fp16 hi operand IS the stashed activation
                 reinterpret_cast<unsigned(&)[4]>(tmp[cb])[j / 2] = hi;
-                if (OP % 4 == 3) *reinterpret_cast<h8*>(stash[cb] + (slot + s) * 1024) = tmp[cb];
+                if (OP % 4 == 3) __builtin_nontemporal_store(tmp[cb], reinterpret_cast<h8*>(stash[cb] + (slot + s) * 1024));
+                if (RELU) {     // relu mask of the pair for the dgrad kernel: bit 2*OP / 16 + 2*OP (nfl_plan.h)
+                    unsigned on;
+                    asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(hi), "s"(0x00010001u));
+                    m32[cb] = OP == 0 ? on : ((on << (2 * OP)) | m32[cb]);
+                    if (OP == 7) __builtin_nontemporal_store(m32[cb], reinterpret_cast<unsigned*>(mstash[cb] + mword * 256));
+                }
             }
         }
     }
@@ -437,8 +474,10 @@ template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool S
 NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
                        const h8 (&inA)[NINA][NCB][NP], int ksA0,
                        const h8 (&inB)[NINB][NCB][NP], int ksB0,
-                       h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&stash)[NCB], int slot0) {
+                       h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&stash)[NCB], int slot0,
+                       char* const (&mstash)[NCB], int mw0) {
     constexpr int NK = NKA + NKB;
+    constexpr int NST = (2 + (RELU ? 1 : 0)) * NCB;      // stash stores of one tile's epilogue
     f16v acc[2][NCB];
     const char* wl = nullptr;
     auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
@@ -449,11 +488,11 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         // tile i-1 carried the stash stores of tile i-2's epilogue, issued after this chunk's pieces
-        if (i % TPC == 0) wl = ring.template consume<(STASH && TPC == 1 && i >= 2) ? 2 * NCB : 0>();
+        if (i % TPC == 0) wl = ring.template consume<(STASH && TPC == 1 && i >= 2) ? NST : 0>();
         constexpr int frag0 = (i % TPC) * NK;
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         if constexpr (i > 0) {
-            NflActEpi<NP, NCB, RELU, STASH, NOUT> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1)};
+            NflActEpi<NP, NCB, RELU, STASH, NOUT> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1};
             nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
         } else {
             NflNoEpi epi;
@@ -462,7 +501,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         // pieces the k-loop of this chunk did not get to
         if (i % TPC == TPC - 1 || i == NRT - 1) ring.template pieces<((i % TPC) + 1) * NK, Ring::MAXP>();
     });
-    NflActEpi<NP, NCB, RELU, STASH, NOUT> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1)};
+    NflActEpi<NP, NCB, RELU, STASH, NOUT> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1};
     last.all();
     rt += NRT;
 }
@@ -541,6 +580,10 @@ struct NflRenderCfg {
 #ifdef NFL_STAMPS
 #define NFL_NSTAMP 20
 __device__ unsigned long long nfl_stamp_buf[1024 * 4 * NFL_NSTAMP];
+// diagnostic build: copy the per-wave phase cycle totals of the last launch to the host
+extern "C" int nfl_debug_stamps(unsigned long long* host, int n_entries) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nfl_stamp_buf), sizeof(unsigned long long) * n_entries) == hipSuccess ? 0 : -1;
+}
 #define NFL_STAMP(i)                                                      \
     do {                                                                  \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();    \
@@ -614,6 +657,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         h8 P[NKP][NCB][NP];
         h8 X[16][NCB][NP], Y[16][NCB][NP];
         char* st[NCB];        // this lane's slice of the segment's activation record (training forward) or null
+        char* mst[NCB];       // ... and of its relu-mask record
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int g = tile * NSLOT + wave * NCB + cb;        // segment index inside this workgroup
@@ -629,6 +673,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 const bool pok = seg_ok && b < A.n_points;
                 const float* xr = a.d_embedded + (size_t)(b < A.n_points ? b : A.n_points - 1) * A.emb_stride;
                 st[cb] = nullptr;
+                mst[cb] = nullptr;
                 s_ray[cb] = ray;
                 s_idx[cb] = c;
                 s_ok[cb] = pok;
@@ -657,6 +702,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             // bytes, which makes the weight-gradient kernel's transposed LDS reads conflict-free
             st[cb] = STASH ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + (2 * c + h) * 16
                            : nullptr;
+            mst[cb] = STASH ? a.d_act_stash + nfl_msk_offset((size_t)a.n_rays * SPR, NKP)
+                                  + (size_t)(ray0 * SPR + gg) * (NFL_MSK_WORDS * 256) + lane * 4
+                            : nullptr;
             s_ray[cb] = ray;
             s_idx[cb] = ii;
             s_ok[cb] = ok;
@@ -682,21 +730,21 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         // accumulator tiles die immediately
         float o_sig[NCB], o_rgb[NCB][3], o_tr[NCB][5];
         NFL_STAMP(0);
-        nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1));       // L1
+        nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1), mst, nfl_msk_h(1));       // L1
         NFL_STAMP(1);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2));        // L2
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2), mst, nfl_msk_h(2));        // L2
         NFL_STAMP(2);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3));        // L3
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3), mst, nfl_msk_h(3));        // L3
         NFL_STAMP(3);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4));        // L4
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4), mst, nfl_msk_h(4));        // L4
         NFL_STAMP(4);
-        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5));      // L5 (skip)
+        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5), mst, nfl_msk_h(5));      // L5 (skip)
         NFL_STAMP(5);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6));        // L6
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6), mst, nfl_msk_h(6));        // L6
         NFL_STAMP(6);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7));        // L7
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7), mst, nfl_msk_h(7));        // L7
         NFL_STAMP(7);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8));        // L8
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8), mst, nfl_msk_h(8));        // L8
         NFL_STAMP(8);
         {
             f16v hacc[NCB];
@@ -706,7 +754,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         }
         NFL_STAMP(9);
         if (!a.sigma_only) {
-            nfl_dense<NP, NCB, 16, 0, false, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP));   // final (linear)
+            nfl_dense<NP, NCB, 16, 0, false, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP), mst, 0);   // final (linear)
             NFL_STAMP(10);
             {
                 h8 D[5][NCB][NP];
@@ -756,9 +804,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 }
                 NFL_STAMP(11);
                 if (A.has_a)
-                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
+                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
                 else
-                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP));
+                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
             }
             NFL_STAMP(12);
             {
@@ -793,10 +841,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     nfl_split8<NP>(v, T[0][cb]);
                     if (STASH) nfl_stash8(v, st[cb] + nfl_act_tau(NKP) * 1024);
                 }
-                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0, st, nfl_act_g(NKP, 1));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 2));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0, st, nfl_act_g(NKP, 3));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 4));
+                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0, st, nfl_act_g(NKP, 1), mst, nfl_msk_g(1));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 2), mst, nfl_msk_g(2));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0, st, nfl_act_g(NKP, 3), mst, nfl_msk_g(3));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 4), mst, nfl_msk_g(4));
                 f16v hacc[NCB];
                 nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 8, hacc);
 #pragma unroll

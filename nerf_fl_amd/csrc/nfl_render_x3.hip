@@ -10,9 +10,3 @@ extern "C" int nfl_launch_render_x3(const NflPlan* hp, const void* d_plan, const
     return NFL_EINVAL;
 }
 
-#ifdef NFL_STAMPS
-// diagnostic build: copy the per-wave phase cycle totals of the last launches to the host
-extern "C" int nfl_debug_stamps(unsigned long long* host, int n_entries) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(nfl_stamp_buf), sizeof(unsigned long long) * n_entries) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -131,7 +131,7 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
         for (int pp = 0; pp < PW; ++pp)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(psrc[pp] + (size_t)sg * pstride[pp]),
-                (__attribute__((address_space(3))) void*)(smem + s * WG_SLOT + pdst[pp]), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(smem + s * WG_SLOT + pdst[pp]), 16, 0, 2);   // nt: a pure stream, keep it out of L2
     };
 
     // tiles of this wave (clamped into range; duplicates are dropped at the flush)

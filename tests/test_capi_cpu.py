@@ -84,8 +84,8 @@ def test_bwd_plan_structure(L):
     assert L.nfl_bwd_plan_build(C.byref(d), 1, buf, n) == 0
     hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)
     assert hdr2[5] == 1 and hdr2[12] == n_rt + 5 and hdr2[18] == total_ks + 8 + 4 * 16
-    # stash sizes: per 32-sample segment 194 / 189 KiB (+ 4 KiB tail pad)
-    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 194 * 1024 + 4096
+    # stash sizes: per 32-sample segment 194 / 189 KiB (+ 4 KiB tail pad), then 84 relu-mask words x 256 B per segment
+    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 194 * 1024 + 4096 + 8 * 4 * 84 * 256
     assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == (8 * 4 + 1) * 189 * 1024 + 4096
 
 
