@@ -28,8 +28,8 @@
 extern "C" {
 #endif
 
-#define NFL_ABI_VERSION 3
-#define NFL_GMAX_SLOTS 64
+#define NFL_ABI_VERSION 4
+#define NFL_GMAX_SLOTS 1024
 
 enum {
     NFL_OK = 0,
@@ -204,7 +204,7 @@ typedef struct nfl_compbwd_args {
     const float* g_rgb_static;      /* (R,3)  _rgb_fine_static                             */
     const float* g_rgb_transient;   /* (R,3)  _rgb_fine_transient                          */
     float* d_head_grads;            /* out (R*N,9): d/d pre-activation [rgb,sigma,rgb_t,sigma_t,beta] */
-    float* d_gmax;                  /* out (NFL_GMAX_SLOTS = 64 floats): partial maxima of |head gradient| of this pass (zeroed by the call; the consumers take the max) */
+    float* d_gmax;                  /* out (NFL_GMAX_SLOTS = 1024 floats): partial maxima of |head gradient| of this pass (zeroed by the call; the consumers take the max) */
 } nfl_compbwd_args;
 int nfl_composite_backward(const nfl_compbwd_args* args, void* stream);
 
@@ -223,7 +223,7 @@ typedef struct nfl_dgrad_args {
     const float* d_z;               /* (R,N) depths the forward pass used                  */
     const float* d_pe_w_xyz;        /* as given to the forward pass (NULL = ones)          */
     const float* d_pe_w_dir;
-    const float* d_gmax;            /* (64) from nfl_composite_backward: fixes the loss scale of this pass */
+    const float* d_gmax;            /* (1024) from nfl_composite_backward: fixes the loss scale of this pass */
 } nfl_dgrad_args;
 int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
                   const nfl_dgrad_args* args, void* stream);
@@ -239,7 +239,7 @@ typedef struct nfl_field_grads {
  * transient on/off; the caller uploads it verbatim like the other plans). */
 size_t nfl_wgrad_plan_bytes(void);
 int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, void* h_plan, size_t bytes);
-/* d_gmax: the same 64 floats the dgrad of this pass was given (the stashed gradients carry its loss scale) */
+/* d_gmax: the same 1024 floats the dgrad of this pass was given (the stashed gradients carry its loss scale) */
 int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
                   const float* d_gmax, int32_t n_rays, int32_t n_samples, const nfl_field_grads* grads, void* stream);
 

@@ -9,8 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFL_LIB") or os.path.join(_HERE, "libnerf_fl_amd.so")
 
-NFL_ABI_VERSION = 3
-NFL_GMAX_SLOTS = 64
+NFL_ABI_VERSION = 4
+NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
 NFL_NUM_LAYERS = 19

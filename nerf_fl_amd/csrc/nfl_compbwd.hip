@@ -159,12 +159,12 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
     if (a.d_gmax) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, d));
-        // non-negative floats order like their bit patterns; NaN/Inf gradients end up as a huge scale exponent
-        // that nfl_loss_scale_from_bits clamps (the NaNs themselves propagate to the result as in the reference)
-        // almost every wave finds the maximum already at or above its own: look before the (serialising) atomic
-        unsigned* slot = reinterpret_cast<unsigned*>(a.d_gmax) + (blockIdx.x & (NFL_GMAX_SLOTS - 1));
-        if (lane == 0 && __float_as_uint(gmax) > __atomic_load_n(slot, __ATOMIC_RELAXED))
-            atomicMax(slot, __float_as_uint(gmax));
+        // one atomic per wave, spread over NFL_GMAX_SLOTS words: every wave of the grid gets here at about the same
+        // time, so a "look before you leap" load does not filter anything and same-address atomics serialise in L2
+        // (non-negative floats order like their bit patterns; NaN/Inf gradients end up as a huge scale exponent
+        // that nfl_loss_scale_from_bits clamps, and the NaNs themselves propagate to the result as in the reference)
+        if (lane == 0 && gmax > 0.f)
+            atomicMax(reinterpret_cast<unsigned*>(a.d_gmax) + (ray & (NFL_GMAX_SLOTS - 1)), __float_as_uint(gmax));
     }
 }
 

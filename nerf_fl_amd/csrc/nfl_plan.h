@@ -116,7 +116,7 @@ NFL_HD constexpr size_t nfl_msk_offset(size_t n_seg, int nkp) { return n_seg * (
 #define NFL_GRD_HEADS 184
 #define NFL_GRD_SLOTS 189
 
-#define NFL_GMAX_SLOTS 64     // d_gmax is 64 floats: workgroups spread their atomicMax over them, readers take the max
+#define NFL_GMAX_SLOTS 1024     // d_gmax is 1024 floats: workgroups spread their atomicMax over them, readers take the max
 // Loss scale of a backward pass: the power of two that brings max|head gradient| (bits of the fp32 the
 // compositing backward left in d_gmax) to [2^7, 2^8).  fp16 overflows at 65504, so intermediate gradients may
 // grow 256x over the largest head gradient; anything 2^-21 below it is still a normal fp16.  dgrad and

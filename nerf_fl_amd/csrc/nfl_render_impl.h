@@ -389,7 +389,12 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
 // max over the NFL_GMAX_SLOTS words the compositing backward left (bit patterns of non-negative floats order
 // like unsigned integers); wave-uniform result
 NFL_DEV unsigned nfl_gmax_bits(const float* d_gmax) {
-    unsigned v = d_gmax ? reinterpret_cast<const unsigned*>(d_gmax)[threadIdx.x & (NFL_GMAX_SLOTS - 1)] : 0u;
+    unsigned v = 0u;
+    if (d_gmax)
+        for (int i = threadIdx.x & 63; i < NFL_GMAX_SLOTS; i += 64) {
+            const unsigned o = reinterpret_cast<const unsigned*>(d_gmax)[i];
+            v = o > v ? o : v;
+        }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         const unsigned o = __shfl_xor(v, d);

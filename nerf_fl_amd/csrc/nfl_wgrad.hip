@@ -261,7 +261,11 @@ __global__ __launch_bounds__(256) void nfl_wgrad_scale_kernel(const WgTensors T,
     if (p == nullptr || n == 0) return;
     float f = 0.f;
     if (op != 0) {
-        unsigned v = reinterpret_cast<const unsigned*>(gmax)[threadIdx.x & (NFL_GMAX_SLOTS - 1)];
+        unsigned v = 0u;
+        for (int i = threadIdx.x & 63; i < NFL_GMAX_SLOTS; i += 64) {
+            const unsigned o = reinterpret_cast<const unsigned*>(gmax)[i];
+            v = o > v ? o : v;
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             const unsigned o = __shfl_xor(v, d);

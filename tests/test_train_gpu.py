@@ -40,3 +40,4 @@ def test_fit_and_checkpoint(tmp_path):
     tr2 = RayTrainer(dev, N_samples=32, N_importance=32, encode_a=True, encode_t=True, N_vocab=8, batch_size=512, seed=5)
     tr2.load(path)
     assert abs(tr2.validate(val, vrgb, vts) - p1) < 1e-4
+

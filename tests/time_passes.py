@@ -57,7 +57,7 @@ if prec == "f16x3":
     ca.noise_std, ca.n_rays, ca.n_samples, ca.use_transient, ca.white_back = 1.0, R, F, 0, 1
     ca.g_rgb = rnd._ptr(grads[2])
     ca.d_head_grads = rnd._ptr(head)
-    gmax = torch.zeros(64, device=dev)
+    gmax = torch.zeros(1024, device=dev)
     ca.d_gmax = rnd._ptr(gmax)
     print("composite backward    %.3f ms" % timeit(lambda: _lib.check(L.nfl_composite_backward(C.byref(ca), rnd._stream()), "cb")))
     da = _lib.DgradArgs()
