@@ -12,9 +12,8 @@
 // transpose), two reads per MFMA operand, no extra pass over the data.
 //
 // Roofline: HBM.  A 256x256 layer reads 32 KiB per segment for 2 x 64 MFMAs, 128 FLOP/B,
-// far under the MFMA ridge, so the kernel is a stream: 3-slot LDS ring fed by
-// global_load_lds, one barrier per segment, fp32 accumulators for the whole (<=256 x <=352)
-// tile of dW in registers, one fp32 atomic flush per workgroup at the end.
+// far under the MFMA ridge, so the kernel is a stream (wg_body_rs below), with fp32 accumulators
+// for the whole (<=256 x <=352) tile of dW in registers and one fp32 atomic flush per workgroup.
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -101,97 +100,9 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
     }
 }
 
-// PW: DMA pieces per wave per segment; NITW: in tiles per wave.  No branch inside the segment loop:
-// a wave whose share is short works on a clamped (duplicate) tile and drops it at the flush.
-template <int PW, int NITW>
-__device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const int act_slots, const int grd_slots,
-                                        const int seg0, const int seg1, char* smem) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wo = wave % J.n_wo, wi = wave / J.n_wo;
-    const int n_pieces = 2 * (J.n_ot + J.n_it);
-
-    const char* psrc[PW];
-    size_t pstride[PW];
-    int pdst[PW];
-#pragma unroll
-    for (int pp = 0; pp < PW; ++pp) {
-        int p = wave + 4 * pp;
-        p = p < n_pieces ? p : n_pieces - 1;
-        const int t = p >> 1;
-        const bool is_out = t < J.n_ot;
-        const int slot = (is_out ? J.ot[t].slot : J.it[t - J.n_ot].slot) + (p & 1);
-        psrc[pp] = (is_out ? A.grd : A.act) + (size_t)slot * 1024 + lane * 16;
-        pstride[pp] = (size_t)(is_out ? grd_slots : act_slots) * 1024;
-        pdst[pp] = p * WG_PSTRIDE;
-    }
-    auto issue = [&](int seg, int s) __attribute__((always_inline)) {
-        const int sg = seg < seg1 ? seg : seg1 - 1;          // surplus issues re-read the last segment
-#pragma unroll
-        for (int pp = 0; pp < PW; ++pp)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(psrc[pp] + (size_t)sg * pstride[pp]),
-                (__attribute__((address_space(3))) void*)(smem + s * WG_SLOT + pdst[pp]), 16, 0, 2);   // nt: a pure stream, keep it out of L2
-    };
-
-    // tiles of this wave (clamped into range; duplicates are dropped at the flush)
-    int my_ot[WG_NOT], my_it[NITW];
-#pragma unroll
-    for (int a = 0; a < WG_NOT; ++a) my_ot[a] = wo * WG_NOT + a < J.n_ot ? wo * WG_NOT + a : J.n_ot - 1;
-#pragma unroll
-    for (int b = 0; b < NITW; ++b) my_it[b] = wi + b * J.n_wi < J.n_it ? wi + b * J.n_wi : J.n_it - 1;
-
-    f16v acc[WG_NOT][NITW];
-#pragma unroll
-    for (int a = 0; a < WG_NOT; ++a)
-#pragma unroll
-        for (int b = 0; b < NITW; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    float bsum[WG_NOT] = {0.f, 0.f};
-
-    // 4-slot ring, all four slots in flight while the waves wait: a slot is refilled as soon as every wave has
-    // finished reading it (second barrier of the iteration), not one iteration later -- the kernel spends two
-    // thirds of its time waiting for HBM, so what counts is the number of bytes outstanding, not the barrier
-    issue(seg0, 0);
-    issue(seg0 + 1, 1);
-    issue(seg0 + 2, 2);
-    issue(seg0 + 3, 3);
-    int s_read = 0;
-    for (int seg = seg0; seg < seg1; ++seg) {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PW) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* base = smem + s_read * WG_SLOT;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            h8 av[WG_NOT], bv[NITW];
-#pragma unroll
-            for (int a = 0; a < WG_NOT; ++a) av[a] = wg_operand(base + my_ot[a] * WG_TSTRIDE, lane, m);
-#pragma unroll
-            for (int b = 0; b < NITW; ++b) bv[b] = wg_operand(base + (J.n_ot + my_it[b]) * WG_TSTRIDE, lane, m);
-#pragma unroll
-            for (int a = 0; a < WG_NOT; ++a) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)av[a][j];
-                bsum[a] += s;
-            }
-#pragma unroll
-            for (int b = 0; b < NITW; ++b)
-#pragma unroll
-                for (int a = 0; a < WG_NOT; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[a], bv[b], acc[a][b], 0, 0, 0);
-        }
-        // every operand of this segment is in registers: hand the slot back
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue(seg + 4, s_read);
-        s_read = (s_read + 1) & 3;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
+template <int NITW>
+__device__ __forceinline__ void wg_flush(const WgArgs& A, const WgJob& J, f16v (&acc)[WG_NOT][NITW], float (&bsum)[WG_NOT],
+                                         const int wo, const int wi, const int lane) {
     // flush: fp32 atomics into the nn.Linear-layout gradient tensors (still carrying the loss scale: a VALU
     // multiply here would pull every accumulator through the 256 arch VGPRs and spill inside the streaming
     // loop; nfl_wgrad_scale_kernel divides the finished tensors instead)
@@ -225,6 +136,132 @@ __device__ __forceinline__ void wg_body(const WgArgs& A, const WgJob& J, const i
     }
 }
 
+typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wg_gload(wg_u4& dst, const char* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr));
+}
+// wait until at most N vector-memory operations are outstanding; the register set rides through so its users stay below
+template <int N, int PW>
+__device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
+    static_assert(N < 64, "vmcnt is a 6-bit counter");
+    static_assert(PW == 4 || PW == 5 || PW == 8, "piece counts the dispatcher uses");
+    if constexpr (PW == 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
+    else if constexpr (PW == 5)
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(N));
+    else
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
+                     "+v"(r[6]), "+v"(r[7]) : "n"(N));
+}
+
+// The stream is staged through REGISTERS.  An LDS-DMA ring (the first design: 4 slots of 32-40 KiB, 1.43 ms per
+// fine pass) caps the bytes a workgroup keeps outstanding at what fits in the 160 KB of LDS, and this kernel waits
+// for HBM ~60 % of the time, so bytes in flight are what counts.  Here every wave keeps D segments of its own
+// 1 KiB pieces in flight in registers (nontemporal global_load_dwordx4, 4 VGPRs per piece; PW = pieces per wave
+// per segment, NITW = in tiles per wave), copies the oldest set into a 2-slot LDS double buffer with
+// ds_write_b128 when its turn comes, and re-issues loads into the freed registers at once: 1.13 ms = 5.7 TB/s.
+// One barrier per segment; no branch inside a segment: a wave whose share is short works on a clamped
+// (duplicate) tile and drops it at the flush.
+template <int PW, int NITW, int D>
+__device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, const int act_slots, const int grd_slots,
+                                           const int seg0, const int seg1, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wo = wave % J.n_wo, wi = wave / J.n_wo;
+    const int n_pieces = 2 * (J.n_ot + J.n_it);
+
+    const char* psrc[PW];
+    size_t pstride[PW];
+    int pdst[PW];
+#pragma unroll
+    for (int pp = 0; pp < PW; ++pp) {
+        int p = wave + 4 * pp;
+        p = p < n_pieces ? p : n_pieces - 1;
+        const int t = p >> 1;
+        const bool is_out = t < J.n_ot;
+        const int slot = (is_out ? J.ot[t].slot : J.it[t - J.n_ot].slot) + (p & 1);
+        psrc[pp] = (is_out ? A.grd : A.act) + (size_t)slot * 1024 + lane * 16;
+        pstride[pp] = (size_t)(is_out ? grd_slots : act_slots) * 1024;
+        pdst[pp] = p * WG_PSTRIDE + lane * 16;
+    }
+    // The loads and their waits are hand-issued: left to hipcc the loop header gets an s_waitcnt vmcnt(0), which
+    // drains all D segments once per trip.  VMEM operations return in order, so "all but the (D-1)*PW youngest"
+    // is exactly "the oldest register set has landed"; nothing else in the loop touches vector memory.
+    wg_u4 R[D][PW];
+    auto gload = [&](int seg, auto DD) __attribute__((always_inline)) {
+        constexpr int d = decltype(DD)::value;
+        const int sg = seg < seg1 ? seg : seg1 - 1;          // surplus loads re-read the last segment
+#pragma unroll
+        for (int pp = 0; pp < PW; ++pp) wg_gload(R[d][pp], psrc[pp] + (size_t)sg * pstride[pp]);
+    };
+
+    int my_ot[WG_NOT], my_it[NITW];
+#pragma unroll
+    for (int a = 0; a < WG_NOT; ++a) my_ot[a] = wo * WG_NOT + a < J.n_ot ? wo * WG_NOT + a : J.n_ot - 1;
+#pragma unroll
+    for (int b = 0; b < NITW; ++b) my_it[b] = wi + b * J.n_wi < J.n_it ? wi + b * J.n_wi : J.n_it - 1;
+
+    f16v acc[WG_NOT][NITW];
+#pragma unroll
+    for (int a = 0; a < WG_NOT; ++a)
+#pragma unroll
+        for (int b = 0; b < NITW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float bsum[WG_NOT] = {0.f, 0.f};
+    // tile offsets inside a slot, in registers: J lives in global memory and the asm memory clobbers below would
+    // otherwise make the loop re-load J.n_ot (a vmcnt(0) wait per segment)
+    int ot_off[WG_NOT], it_off[NITW];
+#pragma unroll
+    for (int a = 0; a < WG_NOT; ++a) ot_off[a] = my_ot[a] * WG_TSTRIDE;
+#pragma unroll
+    for (int b = 0; b < NITW; ++b) it_off[b] = (J.n_ot + my_it[b]) * WG_TSTRIDE;
+
+    wg_static_for<0, D>([&](auto DD) __attribute__((always_inline)) { gload(seg0 + decltype(DD)::value, DD); });
+    for (int base = seg0; base < seg1; base += D) {
+        wg_static_for<0, D>([&](auto DD) __attribute__((always_inline)) {
+            constexpr int d = decltype(DD)::value;
+            const int seg = base + d;
+            if (seg < seg1) {                                     // uniform
+                char* slot = smem + ((seg - seg0) & 1) * WG_SLOT;
+                wg_landed<(D - 1) * PW, PW>(R[d]);
+#pragma unroll
+                for (int pp = 0; pp < PW; ++pp) *reinterpret_cast<wg_u4*>(slot + pdst[pp]) = R[d][pp];
+                gload(seg + D, DD);
+                __builtin_amdgcn_sched_barrier(0);
+                // raw barrier: __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0), which would
+                // drain the D segments in flight; only the LDS writes have to be complete here
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const char* base_l = slot;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    h8 av[WG_NOT], bv[NITW];
+#pragma unroll
+                    for (int a = 0; a < WG_NOT; ++a) av[a] = wg_operand(base_l + ot_off[a], lane, m);
+#pragma unroll
+                    for (int b = 0; b < NITW; ++b) bv[b] = wg_operand(base_l + it_off[b], lane, m);
+#pragma unroll
+                    for (int a = 0; a < WG_NOT; ++a) {
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sacc += (float)av[a][j];
+                        bsum[a] += sacc;
+                    }
+#pragma unroll
+                    for (int b = 0; b < NITW; ++b)
+#pragma unroll
+                        for (int a = 0; a < WG_NOT; ++a)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[a], bv[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus loads still target live registers
+    wg_flush<NITW>(A, J, acc, bsum, wo, wi, lane);
+}
+
 __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgPlan& P = *A.plan;
@@ -238,14 +275,14 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     const int pw = P.cost[j];
     const int nitw = (J.n_it + J.n_wi - 1) / J.n_wi;       // in tiles per wave
     if (pw <= 4) {
-        if (nitw <= 1) wg_body<4, 1>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-        else wg_body<4, 2>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        if (nitw <= 1) wg_body_rs<4, 1, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        else wg_body_rs<4, 2, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
     } else if (pw <= 5) {
-        wg_body<5, 2>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        wg_body_rs<5, 2, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
     } else {
-        if (nitw <= 5) wg_body<8, 5>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-        else if (nitw <= 6) wg_body<8, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-        else wg_body<8, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        if (nitw <= 5) wg_body_rs<8, 5, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        else if (nitw <= 6) wg_body_rs<8, 6, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        else wg_body_rs<8, 8, 5>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
     }
 }
 
@@ -436,7 +473,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_SLOT) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_SLOT) != hipSuccess)
             return NFL_ENODEV;
         attr_set = true;
     }
@@ -450,7 +487,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, 2 * NFL_NUM_LAYERS), dim3(256), 0, s, T, 0, d_gmax);
     if (n_rays == 0) return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
-    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 4 * WG_SLOT, s, A);
+    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, A);
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, 2 * NFL_NUM_LAYERS), dim3(256), 0, s, T, 1, d_gmax);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

@@ -151,3 +151,38 @@ def test_learnable_pose_gradients_end_to_end():
         g_h, g_o = getattr(pose_h, name).grad.cpu(), getattr(pose_o, name).grad
         assert g_o.abs().max() > 0
         assert (g_h - g_o).abs().max().item() <= GTOL * g_o.abs().max().item(), (name, g_h, g_o)
+
+
+@pytest.mark.parametrize("log2_factor", [-30, 20])
+def test_loss_scale_makes_backward_magnitude_invariant(log2_factor):
+    """The MLP backward runs in fp16 under a device-chosen power-of-two loss scale.  A loss
+    multiplied by 2^k must therefore give gradients multiplied by 2^k -- far outside fp16's own range -- up to the
+    summation-order noise of the fp32 atomics."""
+    import gpu_util
+    from nerf_fl_amd import PosEmbedding, render_rays
+    dev = gpu_util.DEV
+    R, S, I = 64, 32, 32
+    spec_c, spec_f = orc.FieldSpec("coarse"), orc.FieldSpec("fine", encode_appearance=True, encode_transient=True, beta_min=0.1)
+    P_c, P_f = orc.make_field_params(spec_c, 61, "sharp"), orc.make_field_params(spec_f, 62, "sharp")
+    g = torch.Generator().manual_seed(7)
+    rays, target = orc.make_rays(R, 63).to(dev), torch.rand(R, 3, generator=g).to(dev)
+    a_emb, t_emb = torch.randn(R, 48, generator=g).to(dev), torch.randn(R, 16, generator=g).to(dev)
+    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
+    ts = torch.zeros(R, dtype=torch.long, device=dev)
+
+    def grads(factor):
+        models = {"coarse": gpu_util.module_from(spec_c, P_c), "fine": gpu_util.module_from(spec_f, P_f)}
+        a_h, t_h = a_emb.clone().requires_grad_(True), t_emb.clone().requires_grad_(True)
+        out = render_rays(models, emb, rays, ts, S, False, 0.0, 0.0, I, 32768, True, False, a_embedded=a_h, t_embedded=t_h)
+        (sum(orc.nerfw_loss(out, target).values()) * factor).backward()
+        gs = {f"{t}.{n}": p.grad for t, m in models.items() for n, p in m.named_parameters() if p.grad is not None}
+        gs["a"], gs["t"] = a_h.grad, t_h.grad
+        return gs
+
+    base, scaled = grads(1.0), grads(2.0 ** log2_factor)
+    assert set(base) == set(scaled)
+    for k in base:
+        assert torch.isfinite(scaled[k]).all(), k
+        ref = base[k].abs().max().item()
+        err = (scaled[k] * 2.0 ** (-log2_factor) - base[k]).abs().max().item()
+        assert err <= 1e-4 * ref + 1e-12, (k, err, ref)
