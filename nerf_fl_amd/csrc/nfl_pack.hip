@@ -38,9 +38,14 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
         reinterpret_cast<float*>(a.out + P.bias_off)[t * 32 + lane] = v;
         return;
     }
-    // locate the row tile containing this k-step (n_rt <= 112: linear scan is fine)
+    // locate the row tile containing this k-step: last t with rt[t].frag_off <= gks.  Binary search: every probe is
+    // a dependent load from the plan in global memory, and a linear scan made this kernel 24 us of pure latency
     int t = 0;
-    while (t + 1 < P.n_rt && P.rt[t + 1].frag_off <= gks) ++t;
+    for (int hi = P.n_rt; hi - t > 1;) {
+        const int mid = (t + hi) >> 1;
+        if (P.rt[mid].frag_off <= gks) t = mid;
+        else hi = mid;
+    }
     const NflRowTile& rt = P.rt[t];
     int ks = gks - rt.frag_off;
     int s = 0;

@@ -29,6 +29,7 @@ def test_fit_and_checkpoint(tmp_path):
         loss, train_psnr = tr.fit_epoch(rays, rgb, ts)
         assert loss == loss                      # not NaN
     p1 = tr.validate(val, vrgb, vts)
+    print("PSNR before / after 3 epochs:", p0, p1)
     assert p1 > p0 + 3.0, (p0, p1)
 
     # checkpoint keys carry the reference's prefixes (train.py:51-76; utils/__init__.py:67-88)
