@@ -248,7 +248,7 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     if want_z:
         out["z"] = new(R, n_samples)
     if field_raw or stash:
-        out["field_raw"] = torch.zeros(R * n_samples, 9, dtype=torch.float32, device=dev)
+        out["field_raw"] = torch.empty(R * n_samples, 9, dtype=torch.float32, device=dev)
     if stash:
         nb = _lib.lib().nfl_act_stash_bytes(C.byref(field.desc), R, n_samples)
         out["act_stash"] = torch.empty(nb, dtype=torch.uint8, device=dev)
