@@ -166,6 +166,12 @@ int nfl_field_forward(const void* h_plan, const void* d_plan, const void* d_pack
 /* reference PosEmbedding / BarfPosEmbedding.forward (models/nerf.py:19-32, 61-77): d_x (n,3) ->
  * d_out (n, 6*n_freqs+3); d_w (n_freqs) BARF weights or NULL */
 int nfl_posenc(const float* d_x, int32_t n, int32_t n_freqs, const float* d_w, float* d_out, void* stream);
+/* reference datasets/ray_utils.py:5-55 (get_ray_directions + get_rays) for `count` pixels of a frame of width `width`,
+ * starting at row-major pixel index `start`: camera direction [(i-cx)/fx, -(j-cy)/fy, -1] (no half-pixel), rotated by
+ * c2w[:, :3] and normalised; origin c2w[:, 3].  h_c2w: 12 floats, 3x4 row-major, on the HOST.  d_rays (count, 8) =
+ * [origin, direction, near, far], the matrix nfl_render_pass takes. */
+int nfl_gen_rays(const float* h_c2w, float fx, float fy, float cx, float cy, int32_t width, int64_t start,
+                 int32_t count, float near, float far, float* d_rays, void* stream);
 
 /* ---- backward (training) ---------------------------------------------------
  * The reference gets its gradients from autograd replaying ~100 ATen kernels per

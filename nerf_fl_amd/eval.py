@@ -84,3 +84,27 @@ def batched_inference(models, embeddings, rays, ts, N_samples, N_importance, use
         for k, v in out.items():
             results.setdefault(k, []).append(v)
     return {k: torch.cat(v, 0) for k, v in results.items()}
+
+
+def frame_rays(c2w, K, H, W, near, far, device, start=0, count=None):
+    """(count, 8) ray matrix [o, d, near, far] of pixels [start, start + count) of an H x W frame seen from pose `c2w`
+    (3|4, 4) with intrinsics `K` (3, 3), generated on the device by nfl_gen_rays (reference datasets/ray_utils.py:5-55
+    + the near/far columns the datasets append, e.g. blender.py:65-69).  Only the 12 pose floats cross the bus."""
+    import ctypes as C
+
+    from . import _lib
+    count = H * W - start if count is None else int(count)
+    if start < 0 or count < 0 or start + count > H * W:
+        raise ValueError("pixel range outside the frame")
+    c2w = torch.as_tensor(c2w, dtype=torch.float32).cpu()[:3, :4].contiguous()
+    K = torch.as_tensor(K, dtype=torch.float32).cpu()
+    pose = (C.c_float * 12)(*c2w.reshape(-1).tolist())
+    dev = torch.device(device)
+    rays = torch.empty(count, 8, dtype=torch.float32, device=dev)
+    if count == 0:
+        return rays
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nfl_gen_rays(pose, float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), int(W),
+                                           int(start), count, float(near), float(far), C.c_void_p(rays.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nfl_gen_rays")
+    return rays

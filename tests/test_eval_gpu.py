@@ -35,3 +35,26 @@ def test_batched_inference_matches_direct(use_graph):
     for k in exp:
         assert got[k].shape == exp[k].shape
         assert torch.equal(got[k], exp[k]), k
+
+
+def test_frame_rays_match_ray_utils_restatement():
+    """nfl_gen_rays against the torch restatement of datasets/ray_utils.py (nerf_fl_amd.poses, itself checked on CPU in
+    test_poses_cpu.py): whole frame and a ragged pixel range."""
+    import math
+
+    from nerf_fl_amd.eval import frame_rays
+    from nerf_fl_amd.poses import get_ray_directions, get_rays, make_c2w
+    H, W = 37, 29
+    focal = 0.5 * W / math.tan(0.5 * 0.6911)
+    K = torch.tensor([[focal, 0, W / 2], [0, focal * 1.03, H / 2 - 0.25], [0, 0, 1]], dtype=torch.float32)
+    c2w = make_c2w(torch.tensor([0.3, -0.5, 0.2]), torch.tensor([0.4, -1.1, 3.7]))[:3]
+    d = get_ray_directions(H, W, K).reshape(-1, 3)
+    o_ref, d_ref = get_rays(d, c2w)
+    exp = torch.cat([o_ref, d_ref, torch.full((H * W, 1), 2.0), torch.full((H * W, 1), 6.0)], 1)
+    got = frame_rays(c2w, K, H, W, 2.0, 6.0, "cuda:0").cpu()
+    assert got.shape == exp.shape
+    assert (got - exp).abs().max().item() <= 2e-7
+    assert torch.equal(got[:, 6:], exp[:, 6:]) and torch.equal(got[:, :3], exp[:, :3])
+    part = frame_rays(c2w, K, H, W, 2.0, 6.0, "cuda:0", start=101, count=333).cpu()
+    assert torch.equal(part, got[101:434])
+    assert frame_rays(c2w, K, H, W, 2.0, 6.0, "cuda:0", start=5, count=0).shape == (0, 8)
