@@ -454,13 +454,14 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     A.grd = d_grad_stash;
     A.n_seg = n_rays * ((n_samples + 31) / 32);
     A.g = *grads;
-    // two workgroups' worth of work per CU, dealt to the jobs in proportion to their streamed bytes
+    // one workgroup per CU, dealt to the jobs in proportion to their streamed bytes
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     const int nj = hp->n_jobs;
     int total_cost = 0;
     for (int j = 0; j < nj; ++j) total_cost += hp->cost[j];
-    const int budget = 2 * ncu;
+    const int budget = ncu;     // one resident workgroup per CU: a second round only repeats the pipeline fill / drain
+                                // (measured 1.06 / 1.14 / 1.23 / 1.32 ms for 1 / 2 / 3 / 4 workgroups per CU)
     int acc_wg = 0;
     for (int j = 0; j < nj; ++j) {
         int n = (int)((long long)budget * hp->cost[j] / total_cost);
