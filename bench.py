@@ -116,7 +116,8 @@ def main():
 
     target = torch.rand(R_PER_GPU, 3, device=dev)
     params = [p for m in models.values() for p in m.parameters()]
-    opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)
+    from nerf_fl_amd.train import Adam          # torch.optim.Adam's arithmetic in one launch (C ABI nfl_adam_step)
+    opt = Adam(params, lr=5e-4, eps=1e-8)
     from nerf_fl_amd import parallel
 
     def render_step():

@@ -249,6 +249,20 @@ int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, v
 int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
                   const float* d_gmax, int32_t n_rays, int32_t n_samples, const nfl_field_grads* grads, void* stream);
 
+/* ---- optimiser step (reference utils/__init__.py:30-32: torch.optim.Adam(lr, eps=1e-8), no weight decay, no
+ * amsgrad) over up to NFL_ADAM_MAX_TENSORS fp32 tensors in one launch.  `step` is the 1-based count of this update
+ * (bias corrections 1 - beta^step); a tensor whose grad pointer is NULL is left untouched. */
+#define NFL_ADAM_MAX_TENSORS 64
+typedef struct nfl_adam_tensors {
+    float*       param[NFL_ADAM_MAX_TENSORS];
+    const float* grad[NFL_ADAM_MAX_TENSORS];
+    float*       exp_avg[NFL_ADAM_MAX_TENSORS];
+    float*       exp_avg_sq[NFL_ADAM_MAX_TENSORS];
+    int32_t      numel[NFL_ADAM_MAX_TENSORS];
+} nfl_adam_tensors;
+int nfl_adam_step(const nfl_adam_tensors* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
+                  int32_t step, void* stream);
+
 /* ---- hierarchical sampling (reference sample_pdf, rendering.py:7-46, plus the
  * concat + sort of rendering.py:267-272) -------------------------------------
  * d_z_coarse (R,S), d_weights_coarse (R,S); d_u (R,I) or NULL with d_u_row (I)

@@ -81,6 +81,15 @@ class DgradArgs(C.Structure):
     ]
 
 
+NFL_ADAM_MAX_TENSORS = 64
+
+
+class AdamTensors(C.Structure):
+    _fields_ = [("param", C.c_void_p * NFL_ADAM_MAX_TENSORS), ("grad", C.c_void_p * NFL_ADAM_MAX_TENSORS),
+                ("exp_avg", C.c_void_p * NFL_ADAM_MAX_TENSORS), ("exp_avg_sq", C.c_void_p * NFL_ADAM_MAX_TENSORS),
+                ("numel", C.c_int32 * NFL_ADAM_MAX_TENSORS)]
+
+
 class FieldGrads(C.Structure):
     _fields_ = [("weight", C.c_void_p * NFL_NUM_LAYERS), ("bias", C.c_void_p * NFL_NUM_LAYERS)]
 
@@ -110,6 +119,8 @@ SYMBOLS = [
     ("nfl_wgrad_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),
     ("nfl_mlp_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                 C.POINTER(FieldGrads), C.c_void_p]),
+    ("nfl_adam_step", C.c_int, [C.POINTER(AdamTensors), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                C.c_void_p]),
     ("nfl_abi_version", C.c_int, []),
     ("nfl_version", C.c_char_p, []),
     ("nfl_strerror", C.c_char_p, [C.c_int]),

@@ -406,6 +406,7 @@ class _RenderRaysFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, rays, a_emb, t_emb, *params):
+        ctx.set_materialize_grads(False)     # outputs the loss does not use arrive as None, not as zero tensors to fill and read
         rays = _f32c(rays, "rays")
         result, saved = _forward(cfg, rays, None if a_emb is None else _f32c(a_emb, "a_embedded"),
                                  None if t_emb is None else _f32c(t_emb, "t_embedded"), train=True)

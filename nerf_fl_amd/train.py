@@ -23,7 +23,7 @@ from . import parallel
 from .nerf import NeRF, PosEmbedding
 from .rendering import render_rays
 
-__all__ = ["NerfWLoss", "psnr", "RayTrainer"]
+__all__ = ["NerfWLoss", "psnr", "Adam", "RayTrainer"]
 
 
 class NerfWLoss(nn.Module):
@@ -48,6 +48,59 @@ class NerfWLoss(nn.Module):
 
 def psnr(pred, gt):
     return -10.0 * torch.log10(((pred - gt) ** 2).mean())
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam(lr, betas, eps) -- no weight decay, no amsgrad, the reference's settings
+    (utils/__init__.py:30-32) -- with the whole step in ONE kernel launch (C ABI `nfl_adam_step`).  A regular
+    torch Optimizer otherwise: param_groups (LR schedulers work), state[p] = {step, exp_avg, exp_avg_sq} with
+    torch's names, so state_dict()s are interchangeable with torch.optim.Adam's."""
+
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        import ctypes as C
+
+        from . import _lib
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        L = _lib.lib()
+        for group in self.param_groups:
+            todo = {}                            # (device, step) -> list of (p, grad, m, v)
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or p.grad.is_sparse:
+                    raise RuntimeError("nerf_fl_amd.train.Adam: dense fp32 parameters on a ROCm device only")
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] = int(st["step"]) + 1
+                if not p.is_contiguous():
+                    raise RuntimeError("nerf_fl_amd.train.Adam: parameters must be contiguous")
+                todo.setdefault((p.device, st["step"]), []).append((p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"]))
+            b1, b2 = group["betas"]
+            for (dev, step), items in todo.items():
+                with torch.cuda.device(dev):
+                    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    for i0 in range(0, len(items), _lib.NFL_ADAM_MAX_TENSORS):
+                        chunk = items[i0:i0 + _lib.NFL_ADAM_MAX_TENSORS]
+                        t = _lib.AdamTensors()
+                        for k, (p, g, m, v) in enumerate(chunk):
+                            t.param[k], t.grad[k], t.exp_avg[k], t.exp_avg_sq[k] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+                            t.numel[k] = p.numel()
+                        _lib.check(L.nfl_adam_step(C.byref(t), len(chunk), float(group["lr"]), float(b1), float(b2),
+                                                   float(group["eps"]), step, stream), "nfl_adam_step")
+                        # the kernel wrote the parameters behind autograd's back: bump their version counters, which
+                        # is what tells render_rays to re-pack the weight streams (and autograd to refuse stale graphs)
+                        torch.autograd.graph.increment_version([p for p, _, _, _ in chunk])
+        return loss
 
 
 class RayTrainer:
@@ -76,9 +129,10 @@ class RayTrainer:
                                        beta_min=beta_min).to(self.dev)
             self.modules["nerf_fine"] = self.models["fine"]
         self.params = [p for m in self.modules.values() for p in m.parameters()]
-        # (torch's fused=True Adam is not used: on this ROCm build it left the parameters almost unchanged in
-        # tests/test_train_gpu.py -- validation PSNR 26.89 -> 26.93 instead of 35.9 after the same 24 steps)
-        self.opt = torch.optim.Adam(self.params, lr=lr, eps=1e-8)
+        # one-launch Adam.  (torch's own fused=True variant is not an option here: it updates the parameters without
+        # moving their version counters, so render_rays never re-packed its weight streams and kept rendering with
+        # the initial weights -- tests/test_train_gpu.py: validation PSNR 26.89 -> 26.93 instead of 35.9)
+        self.opt = Adam(self.params, lr=lr, eps=1e-8) if self.dev.type == "cuda" else torch.optim.Adam(self.params, lr=lr, eps=1e-8)
         if lr_scheduler == "cosine":
             self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=num_epochs, eta_min=1e-8)
         elif lr_scheduler == "steplr":

@@ -43,7 +43,8 @@ out = {}
 R = 4096
 models, emb = models_for(True, True, 100)
 params = [p for m in list(models.values()) + [emb["a"], emb["t"]] for p in m.parameters()]
-opt = torch.optim.Adam(params, lr=5e-4, eps=1e-8)
+from nerf_fl_amd.train import Adam
+opt = Adam(params, lr=5e-4, eps=1e-8)
 rays, ts = orc.make_rays(R, 100).to(dev), torch.randint(0, 100, (R,), device=dev)
 target, loss_fn = torch.rand(R, 3, device=dev), NerfWLoss()
 
