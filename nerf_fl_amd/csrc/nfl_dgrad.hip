@@ -8,7 +8,7 @@
 // to fp16 they are the B operand of the next product; W^T streams through the LDS ring
 // as pre-packed fp16 fragments.  Mixed precision with a LOSS SCALE: every gradient in
 // this kernel is multiplied by the power of two S = nfl_loss_scale_from_bits(*d_gmax)
-// (max |head gradient| -> [2^7, 2^8)), so that fp16's 5-bit exponent is spent around the
+// (max |head gradient| -> [2^5, 2^6)), so that fp16's 5-bit exponent is spent around the
 // values that matter whatever the magnitude of the loss; everything that leaves the
 // kernel in fp32 (latent / ray gradients) is multiplied by 1/S, and the gradient stash
 // keeps the scaled fp16 values for the weight-gradient GEMMs, which divide by S at the end.

@@ -448,12 +448,20 @@ struct NflActEpi {
             reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
             if (STASH) {        // the fp16 hi operand IS the stashed activation
                 reinterpret_cast<unsigned(&)[4]>(tmp[cb])[j / 2] = hi;
+#ifdef NFL_ABL_NOSTASHST
+                if (OP % 4 == 3) asm volatile("" :: "v"(tmp[cb]));
+#else
                 if (OP % 4 == 3) __builtin_nontemporal_store(tmp[cb], reinterpret_cast<h8*>(stash[cb] + (slot + s) * 1024));
+#endif
                 if (RELU) {     // relu mask of the pair for the dgrad kernel: bit 2*OP / 16 + 2*OP (nfl_plan.h)
                     unsigned on;
                     asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(hi), "s"(0x00010001u));
                     m32[cb] = OP == 0 ? on : ((on << (2 * OP)) | m32[cb]);
+#ifdef NFL_ABL_NOSTASHST
+                    if (OP == 7) asm volatile("" :: "v"(m32[cb]));
+#else
                     if (OP == 7) __builtin_nontemporal_store(m32[cb], reinterpret_cast<unsigned*>(mstash[cb] + mword * 256));
+#endif
                 }
             }
         }
