@@ -116,7 +116,8 @@ def main():
 
     target = torch.rand(R_PER_GPU, 3, device=dev)
     params = [p for m in models.values() for p in m.parameters()]
-    from nerf_fl_amd.train import Adam          # torch.optim.Adam's arithmetic in one launch (C ABI nfl_adam_step)
+    from nerf_fl_amd.train import Adam, NerfWLoss   # torch.optim.Adam's arithmetic in one launch (C ABI nfl_adam_step)
+    loss_fn = NerfWLoss()
     opt = Adam(params, lr=5e-4, eps=1e-8)
     from nerf_fl_amd import parallel
 
@@ -127,7 +128,7 @@ def main():
     def train_step():
         opt.zero_grad(set_to_none=True)
         res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, True, False)
-        loss = 0.5 * ((res["rgb_coarse"] - target) ** 2).mean() + 0.5 * ((res["rgb_fine"] - target) ** 2).mean()
+        loss = sum(loss_fn(res, target).values())      # c_l + f_l (losses.py:35-41), forward and backward one launch each
         loss.backward()
         if dist is not None:
             parallel.all_reduce_gradients(params)

@@ -263,6 +263,29 @@ typedef struct nfl_adam_tensors {
 int nfl_adam_step(const nfl_adam_tensors* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
                   int32_t step, void* stream);
 
+/* ---- NerfWLoss (reference losses.py:35-50) on the renderer's outputs, forward and backward in one launch each.
+ * Terms (d_losses[4], zeroed by nfl_loss_forward): c_l, f_l, b_l, s_l; f_l uses beta when d_beta != NULL
+ * (then d_rgb_fine is required; b_l and, with d_transient_sigmas, s_l are produced too).
+ * nfl_loss_backward writes the gradients of sum_k *d_grad_loss[k] * loss_k (a NULL entry counts as 0) w.r.t. rgb_coarse,
+ * rgb_fine, beta and transient_sigmas (the last one is the constant coef*lambda_u/(R*N) per element). */
+typedef struct nfl_loss_args {
+    const float* d_rgb_coarse;        /* (R,3)                                  */
+    const float* d_rgb_fine;          /* (R,3) or NULL (coarse-only rendering)  */
+    const float* d_beta;              /* (R) or NULL                            */
+    const float* d_transient_sigmas;  /* (R,N) or NULL                          */
+    const float* d_target;            /* (R,3)                                  */
+    int32_t n_rays, n_samples;        /* n_samples: columns of transient_sigmas */
+    float   coef, lambda_u;           /* losses.py:36: coef = 1, lambda_u = 0.01 */
+    float*  d_losses;                 /* out (4)                                */
+    const float* d_grad_loss[4];      /* device scalars: d total / d {c_l, f_l, b_l, s_l}; NULL = 0 */
+    float*  d_g_rgb_coarse;           /* out (R,3)                              */
+    float*  d_g_rgb_fine;             /* out (R,3)                              */
+    float*  d_g_beta;                 /* out (R)                                */
+    float*  d_g_transient_sigmas;     /* out (R,N) or NULL                      */
+} nfl_loss_args;
+int nfl_loss_forward(const nfl_loss_args* args, void* stream);
+int nfl_loss_backward(const nfl_loss_args* args, void* stream);
+
 /* ---- hierarchical sampling (reference sample_pdf, rendering.py:7-46, plus the
  * concat + sort of rendering.py:267-272) -------------------------------------
  * d_z_coarse (R,S), d_weights_coarse (R,S); d_u (R,I) or NULL with d_u_row (I)

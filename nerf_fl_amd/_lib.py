@@ -90,6 +90,14 @@ class AdamTensors(C.Structure):
                 ("numel", C.c_int32 * NFL_ADAM_MAX_TENSORS)]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [("d_rgb_coarse", C.c_void_p), ("d_rgb_fine", C.c_void_p), ("d_beta", C.c_void_p),
+                ("d_transient_sigmas", C.c_void_p), ("d_target", C.c_void_p), ("n_rays", C.c_int32), ("n_samples", C.c_int32),
+                ("coef", C.c_float), ("lambda_u", C.c_float), ("d_losses", C.c_void_p), ("d_grad_loss", C.c_void_p * 4),
+                ("d_g_rgb_coarse", C.c_void_p), ("d_g_rgb_fine", C.c_void_p), ("d_g_beta", C.c_void_p),
+                ("d_g_transient_sigmas", C.c_void_p)]
+
+
 class FieldGrads(C.Structure):
     _fields_ = [("weight", C.c_void_p * NFL_NUM_LAYERS), ("bias", C.c_void_p * NFL_NUM_LAYERS)]
 
@@ -121,6 +129,8 @@ SYMBOLS = [
                                 C.POINTER(FieldGrads), C.c_void_p]),
     ("nfl_adam_step", C.c_int, [C.POINTER(AdamTensors), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 C.c_void_p]),
+    ("nfl_loss_forward", C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
+    ("nfl_loss_backward", C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     ("nfl_abi_version", C.c_int, []),
     ("nfl_version", C.c_char_p, []),
     ("nfl_strerror", C.c_char_p, [C.c_int]),

@@ -34,6 +34,8 @@ class NerfWLoss(nn.Module):
         self.coef, self.lambda_u = coef, lambda_u
 
     def forward(self, inputs, targets):
+        if targets.is_cuda:
+            return self._fused(inputs, targets)
         ret = {"c_l": 0.5 * ((inputs["rgb_coarse"] - targets) ** 2).mean()}
         if "rgb_fine" in inputs:
             if "beta" not in inputs:
@@ -44,6 +46,64 @@ class NerfWLoss(nn.Module):
                 ret["b_l"] = 3 + torch.log(beta).mean()
                 ret["s_l"] = self.lambda_u * inputs["transient_sigmas"].mean()
         return {k: self.coef * v for k, v in ret.items()}
+
+    def _fused(self, inputs, targets):
+        """Same terms through the C ABI (nfl_loss_forward / nfl_loss_backward): two launches instead of ~16."""
+        rgb_f, beta = inputs.get("rgb_fine"), inputs.get("beta")
+        tsig = inputs.get("transient_sigmas") if beta is not None else None
+        c_l, f_l, b_l, s_l = _FusedNerfWLoss.apply(inputs["rgb_coarse"], rgb_f, beta, tsig, targets, float(self.coef),
+                                                   float(self.lambda_u))
+        ret = {"c_l": c_l}
+        if rgb_f is not None:
+            ret["f_l"] = f_l
+            if beta is not None:
+                ret["b_l"], ret["s_l"] = b_l, s_l
+        return ret
+
+
+class _FusedNerfWLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgb_c, rgb_f, beta, tsig, targets, coef, lambda_u):
+        import ctypes as C
+
+        from . import _lib
+        ctx.set_materialize_grads(False)
+        f32c = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        rgb_c, rgb_f, beta, tsig, targets = f32c(rgb_c), f32c(rgb_f), f32c(beta), f32c(tsig), f32c(targets)
+        a = _lib.LossArgs()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a.d_rgb_coarse, a.d_rgb_fine, a.d_beta, a.d_transient_sigmas, a.d_target = ptr(rgb_c), ptr(rgb_f), ptr(beta), ptr(tsig), ptr(targets)
+        a.n_rays, a.n_samples = rgb_c.shape[0], (tsig.shape[1] if tsig is not None else 0)
+        a.coef, a.lambda_u = coef, lambda_u
+        losses = torch.empty(4, dtype=torch.float32, device=targets.device)
+        a.d_losses = losses.data_ptr()
+        with torch.cuda.device(targets.device):
+            _lib.check(_lib.lib().nfl_loss_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nfl_loss_forward")
+        ctx.saved = (rgb_c, rgb_f, beta, tsig, targets, coef, lambda_u)
+        return losses[0], losses[1], losses[2], losses[3]
+
+    @staticmethod
+    def backward(ctx, *go):
+        import ctypes as C
+
+        from . import _lib
+        rgb_c, rgb_f, beta, tsig, targets, coef, lambda_u = ctx.saved
+        a = _lib.LossArgs()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        a.d_rgb_coarse, a.d_rgb_fine, a.d_beta, a.d_transient_sigmas, a.d_target = ptr(rgb_c), ptr(rgb_f), ptr(beta), ptr(tsig), ptr(targets)
+        a.n_rays, a.n_samples = rgb_c.shape[0], (tsig.shape[1] if tsig is not None else 0)
+        a.coef, a.lambda_u = coef, lambda_u
+        keep = [None if g is None else g.to(torch.float32).contiguous() for g in go]
+        for k in range(4):
+            a.d_grad_loss[k] = ptr(keep[k])
+        g_c = torch.empty_like(rgb_c)
+        g_f = torch.empty_like(rgb_f) if rgb_f is not None else None
+        g_b = torch.empty_like(beta) if beta is not None else None
+        g_s = torch.empty_like(tsig) if tsig is not None else None
+        a.d_g_rgb_coarse, a.d_g_rgb_fine, a.d_g_beta, a.d_g_transient_sigmas = ptr(g_c), ptr(g_f), ptr(g_b), ptr(g_s)
+        with torch.cuda.device(targets.device):
+            _lib.check(_lib.lib().nfl_loss_backward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nfl_loss_backward")
+        return g_c, g_f, g_b, g_s, None, None, None
 
 
 def psnr(pred, gt):

@@ -85,3 +85,34 @@ def test_one_launch_adam_bumps_parameter_versions():
     v0 = p._version
     o.step()
     assert p._version > v0 and not torch.equal(p.detach().cpu(), torch.ones(8))
+
+
+@pytest.mark.parametrize("variant", ["coarse_only", "base", "nerfw"])
+def test_fused_nerfw_loss_matches_reference_formula(variant):
+    """train.NerfWLoss on device tensors (C ABI nfl_loss_forward / nfl_loss_backward) against the oracle's restatement
+    of losses.py:35-50 with autograd, values and gradients, with unequal weights on the terms."""
+    import gpu_util
+    from nerf_fl_amd.train import NerfWLoss
+    dev = gpu_util.DEV
+    g = torch.Generator().manual_seed(5)
+    R, F = 333, 40
+    inp = {"rgb_coarse": torch.rand(R, 3, generator=g)}
+    if variant != "coarse_only":
+        inp["rgb_fine"] = torch.rand(R, 3, generator=g)
+    if variant == "nerfw":
+        inp["beta"] = torch.rand(R, generator=g) * 0.5 + 0.1
+        inp["transient_sigmas"] = torch.rand(R, F, generator=g) * 3
+    target = torch.rand(R, 3, generator=g)
+    wts = {"c_l": 1.0, "f_l": 0.7, "b_l": 1.3, "s_l": 2.0}
+    ref_in = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    ref = orc.nerfw_loss(ref_in, target)
+    sum(wts[k] * v for k, v in ref.items()).backward()
+    hip_in = {k: v.to(dev).requires_grad_(True) for k, v in inp.items()}
+    out = NerfWLoss()(hip_in, target.to(dev))
+    assert list(out.keys()) == list(ref.keys())
+    sum(wts[k] * v for k, v in out.items()).backward()
+    for k in ref:
+        assert abs(out[k].item() - ref[k].item()) <= 2e-6 * max(1.0, abs(ref[k].item())), k
+    for k in inp:
+        e, r = (hip_in[k].grad.cpu() - ref_in[k].grad).abs().max().item(), ref_in[k].grad.abs().max().item()
+        assert e <= 2e-6 * r + 1e-12, (k, e, r)
