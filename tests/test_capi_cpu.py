@@ -106,3 +106,27 @@ def test_render_rays_refuses_cpu_tensors():
     emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU path"):
         render_rays(models, emb, torch.zeros(4, 8), torch.zeros(4, dtype=torch.long), 8)
+
+
+def test_auxiliary_entry_points_validate_arguments(L):
+    """No GPU needed: the entry points around the render pass reject NULL / inconsistent arguments with NFL_EINVAL
+    before touching the device."""
+    assert L.nfl_adam_step(None, 1, 5e-4, 0.9, 0.999, 1e-8, 1, None) == -1
+    t = _lib.AdamTensors()
+    assert L.nfl_adam_step(C.byref(t), _lib.NFL_ADAM_MAX_TENSORS + 1, 5e-4, 0.9, 0.999, 1e-8, 1, None) == -1
+    assert L.nfl_adam_step(C.byref(t), 1, 5e-4, 0.9, 0.999, 1e-8, 0, None) == -1          # steps are 1-based
+    t.numel[0] = 4                                                                          # non-empty tensor without pointers
+    assert L.nfl_adam_step(C.byref(t), 1, 5e-4, 0.9, 0.999, 1e-8, 1, None) == -1
+    assert L.nfl_adam_step(C.byref(_lib.AdamTensors()), 0, 5e-4, 0.9, 0.999, 1e-8, 1, None) == 0
+    assert L.nfl_loss_forward(None, None) == -1 and L.nfl_loss_backward(None, None) == -1
+    a = _lib.LossArgs()
+    a.n_rays = 4
+    assert L.nfl_loss_forward(C.byref(a), None) == -1                                       # no tensors
+    pose = (C.c_float * 12)()
+    assert L.nfl_gen_rays(pose, 1.0, 1.0, 0.0, 0.0, 8, 0, 4, 2.0, 6.0, None, None) == -1   # no output buffer
+    assert L.nfl_gen_rays(pose, 0.0, 1.0, 0.0, 0.0, 8, 0, 4, 2.0, 6.0, C.c_void_p(16), None) == -1   # fx = 0
+    assert L.nfl_gen_rays(pose, 1.0, 1.0, 0.0, 0.0, 8, 0, 0, 2.0, 6.0, C.c_void_p(16), None) == 0    # empty range
+    assert L.nfl_field_forward(None, None, None, None, 4, 90, 0, 0, None, None) == -1
+    assert L.nfl_posenc(None, 4, 10, None, None, None) == -1
+    assert L.nfl_composite_backward(None, None) == -1 and L.nfl_mlp_dgrad(None, None, None, None, None) == -1
+    assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, None, None) == -1
