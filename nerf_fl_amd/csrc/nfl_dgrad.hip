@@ -42,15 +42,16 @@ struct NflDgradCfg {
     static constexpr int KSB = 1024;
     static constexpr int MAXKS = 17;
     static constexpr int WBYTES = MAXKS * KSB;
-    static constexpr int AUXB = 4 * NCB * 256;
+    static constexpr int AUXB = 4 * NCB * 1024;
     static constexpr int SLOT = WBYTES + AUXB;
     static constexpr int MAXP = (WBYTES + 4095) / 4096;
     static constexpr int LDS_TAB = (2 * (NFL_MAX_CHUNKS + 8) + 32) * 4;
     static constexpr int LDS_BYTES = LDS_TAB + 3 * SLOT;
 };
 
-// ring with the per-wave mask pieces: pieces 0..MAXPW-1 are weights, the next one per column block the 256 B
-// (one dword per lane) of that segment's relu-mask word for the tile
+// ring with the per-wave mask pieces: pieces 0..MAXPW-1 are weights, the next one per column block the 1 KiB
+// (four dwords per lane) of that segment's relu-mask words for a group of four tiles, issued with the group's
+// first tile only
 template <int SLOT_BYTES, int WBYTES, int MAXPW, int NCB>
 struct NflRingAux {
     static constexpr int MAXP = MAXPW + NCB;
@@ -65,6 +66,7 @@ struct NflRingAux {
     int wave, lane;
     const char* i_src;
     const char* i_aux[NCB];
+    bool i_mask;
     char* i_dst;
     int i_nbytes;
 
@@ -86,10 +88,11 @@ struct NflRingAux {
         i_src = gsrc + n_off0;
         i_dst = lds + s_issue * SLOT_BYTES;
         const int slot = n_aux < 0 ? 0 : n_aux;
+        i_mask = n_aux >= 0 && (n_aux & 3) == 0;          // this chunk opens a group of four masked tiles
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int sg = seg_issue + cb < seg_last ? seg_issue + cb : seg_last;
-            i_aux[cb] = aux_src + (size_t)sg * seg_stride + slot * 256;
+            i_aux[cb] = aux_src + (size_t)sg * seg_stride + (slot >> 2) * 1024;
         }
         if (c_issue + 1 == n_chunks) {
             c_issue = c_start;
@@ -105,11 +108,9 @@ struct NflRingAux {
 #ifdef DG_ABL_NODMA
         return;
 #endif
-        if constexpr (P < MAXP) {
-            ops += 1;
-            if (P == MAXP - 1) mk1 = ops;
-        }
         if constexpr (P < MAXPW) {
+            ops += 1;
+            if (P == MAXPW - 1 && !i_mask) mk1 = ops;    // last piece of this chunk (unless its mask pieces follow)
             unsigned byte = (unsigned)(wave + 4 * P) * 1024u;
             const unsigned last = (unsigned)i_nbytes - 1024u;
             byte = byte < last ? byte : last;
@@ -118,10 +119,14 @@ struct NflRingAux {
                 (const __attribute__((address_space(1))) void*)(i_src + vo),
                 (__attribute__((address_space(3))) void*)(i_dst + byte), 16, 0, 0);
         } else if constexpr (P < MAXP) {
-            constexpr int cb = P - MAXPW;
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(i_aux[cb] + (unsigned)((threadIdx.x & 63) * 4u)),
-                (__attribute__((address_space(3))) void*)(i_dst + WBYTES + wave * (256 * NCB) + cb * 256), 4, 0, 0);
+            if (i_mask) {                        // uniform
+                ops += 1;
+                if (P == MAXP - 1) mk1 = ops;
+                constexpr int cb = P - MAXPW;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(i_aux[cb] + (unsigned)((threadIdx.x & 63) * 16u)),
+                    (__attribute__((address_space(3))) void*)(i_dst + WBYTES + wave * (1024 * NCB) + cb * 1024), 16, 0, 0);
+            }
         }
     }
     template <int P0, int P1>
@@ -147,11 +152,14 @@ struct NflRingAux {
         // everything up to the last piece of the oldest chunk is done; younger operations may stay in flight
         const int young = ops - mk0;
         mk0 = mk1;               // the chunk issued during the coming tile overwrites mk1 at its last piece
-        if (young >= MAXP + 16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 16) : "memory");
-        else if (young >= MAXP + 12) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 12) : "memory");
-        else if (young >= MAXP + 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 8) : "memory");
-        else if (young >= MAXP + 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP + 4) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(MAXP) : "memory");
+        // buckets on the common chunk (MAXPW weight pieces, no mask pieces) plus whole tiles of stash stores
+        constexpr int B0 = MAXP - NCB;
+        if (young >= B0 + 16) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B0 + 16) : "memory");
+        else if (young >= B0 + 12) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B0 + 12) : "memory");
+        else if (young >= B0 + 8) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B0 + 8) : "memory");
+        else if (young >= B0 + 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B0 + 4) : "memory");
+        else if (young >= B0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(B0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef NFL_STAMPS
         const unsigned long long c1 = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_barrier();
@@ -248,6 +256,7 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
     constexpr int NK = NKA + NKB + NKC;
     f16v acc[2][NCB];
     unsigned mk[2][NCB];
+    unsigned mkq[NCB][4];       // the four mask words of the current group of tiles (arrive with its first tile)
     auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
         constexpr int k = decltype(K)::value;
         if constexpr (k < NKA) return inA[ksA + k][cb][part];
@@ -259,8 +268,16 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         const char* wl = ring.consume();
         dg_zero<NCB>(acc[i & 1]);
         if (MASK) {      // the slot is recycled at the next consume(): take the masks now
+            if constexpr ((i & 3) == 0) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) mk[i & 1][cb] = *reinterpret_cast<const unsigned*>(wl + WB + wave_mask_off + cb * 256);
+                for (int cb = 0; cb < NCB; ++cb) {
+                    typedef unsigned dg_u4 __attribute__((ext_vector_type(4)));
+                    const dg_u4 v = *reinterpret_cast<const dg_u4*>(wl + WB + wave_mask_off + cb * 1024);
+                    mkq[cb][0] = v[0]; mkq[cb][1] = v[1]; mkq[cb][2] = v[2]; mkq[cb][3] = v[3];
+                }
+            }
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) mk[i & 1][cb] = mkq[cb][i & 3];
         }
         if constexpr (i > 0) {
             DgEpi<MASK, NOUT, NCB> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
@@ -385,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     ring.chunk_aux = aux_lds;
     ring.lds = smem + C::LDS_TAB;
     ring.aux_src = a.d_act_stash + nfl_msk_offset((size_t)A.n_seg_total, NKP);
-    ring.seg_stride = (size_t)NFL_MSK_WORDS * 256;
+    ring.seg_stride = (size_t)NFL_MSK_WORDS * 256;      // 21 groups of 1 KiB
     ring.n_chunks = A.n_chunks;
     ring.c_start = A.c_start;
     ring.c_issue = A.c_start;
@@ -434,8 +451,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
 #pragma unroll
             for (int k = 0; k < 9; ++k) hg[cb][k] = (ok && h == 0) ? hp[k] * scale : 0.f;
         }
-        // this wave's mask words in a ring slot (wl carries lane * 16; the words are one dword per lane)
-        const int moff = wave * (256 * NCB) - lane * 12;
+        // this wave's mask words in a ring slot (wl carries lane * 16 = the lane's four words of a group)
+        const int moff = wave * (1024 * NCB);
         // head gradients as natural-order B operands (k = 8h + j)
         h8 dS[1][NCB][1], dC[1][NCB][1], dTs[1][NCB][1], dTc[1][NCB][1], dTb[1][NCB][1];
 #pragma unroll

@@ -99,7 +99,8 @@ NFL_HD constexpr int nfl_act_g(int nkp, int m) { return nkp + 158 + 8 * (m - 1);
 NFL_HD constexpr int nfl_act_slots(int nkp) { return nkp + 190; }
 // relu masks, written by the training-mode forward behind the activation records (one 32-bit word per lane and
 // row tile of a relu layer: bit 2p = value 2p of the lane's 16 accumulators was positive, bit 16+2p = value 2p+1;
-// 256 B per wave and tile instead of the 2 KiB of fp16 activations the dgrad kernel would otherwise re-read):
+// 256 B per wave and tile instead of the 2 KiB of fp16 activations the dgrad kernel would otherwise re-read;
+// record layout [group of 4 tiles][lane][4 words], so one 16 B store / one 1 KiB DMA piece moves four tiles' words):
 //   h1..h8 (8 tiles each) | dirh (4) | g1..g4 (4 each)
 NFL_HD constexpr int nfl_msk_h(int l) { return 8 * (l - 1); }        // l = 1..8
 NFL_HD constexpr int nfl_msk_dirh() { return 64; }

@@ -412,7 +412,7 @@ struct NflNoEpi {
 // Epilogue of an accumulator tile -> the two k-steps (ks, ks+1) of the next layer's B operand
 // (and, in the training forward, the fp16 activation stash), cut into 8 pair-ops per column
 // block so it can be spread over the k-steps of the following tile.
-template <int NP, int NCB, bool RELU, bool STASH, int NOUT>
+template <int NP, int NCB, bool RELU, bool STASH, int NOUT, int MSLOT>
 struct NflActEpi {
     const f16v (&acc)[NCB];
     h8 (&out)[NOUT][NCB][NP];
@@ -421,6 +421,7 @@ struct NflActEpi {
     const int slot;
     char* const (&mstash)[NCB];      // relu-mask records of the lane's segments (training forward)
     const int mword;                 // mask word of this tile
+    unsigned (&mq)[NCB][4];          // the words of the current group of four tiles: one dwordx4 store per group
     h8 tmp[NCB];
     unsigned m32[NCB];
 
@@ -457,11 +458,18 @@ struct NflActEpi {
                     unsigned on;
                     asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(hi), "s"(0x00010001u));
                     m32[cb] = OP == 0 ? on : ((on << (2 * OP)) | m32[cb]);
-#ifdef NFL_ABL_NOSTASHST
-                    if (OP == 7) asm volatile("" :: "v"(m32[cb]));
-#else
-                    if (OP == 7) __builtin_nontemporal_store(m32[cb], reinterpret_cast<unsigned*>(mstash[cb] + mword * 256));
+                    if (OP == 7) {
+                        // mask words are grouped by four tiles (mw0 is a multiple of 4 for every layer): lane l keeps
+                        // words 4g..4g+3 in 16 contiguous bytes, record layout [group][lane][4]
+                        mq[cb][MSLOT] = m32[cb];              // MSLOT = mword & 3, known at compile time
+#ifndef NFL_ABL_NOSTASHST
+                        if (MSLOT == 3) {
+                            typedef unsigned nfl_mq4 __attribute__((ext_vector_type(4)));
+                            const nfl_mq4 v = {mq[cb][0], mq[cb][1], mq[cb][2], mq[cb][3]};
+                            __builtin_nontemporal_store(v, reinterpret_cast<nfl_mq4*>(mstash[cb] + (mword >> 2) * 1024));
+                        }
 #endif
+                    }
                 }
             }
         }
@@ -490,7 +498,9 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
                        h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&stash)[NCB], int slot0,
                        char* const (&mstash)[NCB], int mw0) {
     constexpr int NK = NKA + NKB;
-    constexpr int NST = (2 + (RELU ? 1 : 0)) * NCB;      // stash stores of one tile's epilogue
+    constexpr int NST = 2 * NCB;                         // activation-stash stores of one tile's epilogue (the mask
+                                                         // words go out once per four tiles: not counted, the wait is only stricter)
+    unsigned mq[NCB][4];
     f16v acc[2][NCB];
     const char* wl = nullptr;
     auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
@@ -505,7 +515,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         constexpr int frag0 = (i % TPC) * NK;
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         if constexpr (i > 0) {
-            NflActEpi<NP, NCB, RELU, STASH, NOUT> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1};
+            NflActEpi<NP, NCB, RELU, STASH, NOUT, (i - 1) & 3> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1, mq};
             nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
         } else {
             NflNoEpi epi;
@@ -514,7 +524,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         // pieces the k-loop of this chunk did not get to
         if (i % TPC == TPC - 1 || i == NRT - 1) ring.template pieces<((i % TPC) + 1) * NK, Ring::MAXP>();
     });
-    NflActEpi<NP, NCB, RELU, STASH, NOUT> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1};
+    NflActEpi<NP, NCB, RELU, STASH, NOUT, (NRT - 1) & 3> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1, mq};
     last.all();
     rt += NRT;
 }
@@ -716,7 +726,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             st[cb] = STASH ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + (2 * c + h) * 16
                            : nullptr;
             mst[cb] = STASH ? a.d_act_stash + nfl_msk_offset((size_t)a.n_rays * SPR, NKP)
-                                  + (size_t)(ray0 * SPR + gg) * (NFL_MSK_WORDS * 256) + lane * 4
+                                  + (size_t)(ray0 * SPR + gg) * (NFL_MSK_WORDS * 256) + lane * 16
                             : nullptr;
             s_ray[cb] = ray;
             s_idx[cb] = ii;
