@@ -40,7 +40,7 @@ struct NflDgradCfg {
     static constexpr int NP = 1, NCB = DG_NCB;
     static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
     static constexpr int KSB = 1024;
-    static constexpr int MAXKS = 17;
+    static constexpr int MAXKS = 2 * 17;                 // two row tiles per chunk (one barrier per pair of tiles)
     static constexpr int WBYTES = MAXKS * KSB;
     static constexpr int AUXB = 4 * NCB * 1024;
     static constexpr int SLOT = WBYTES + AUXB;
@@ -247,8 +247,9 @@ struct DgEpi {
     }
 };
 
-// NRT transposed row tiles (one per chunk) with up to three K segments
-template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int NA, int NB, int NC, int NOUT, class Ring>
+// NRT transposed row tiles (two per chunk) with up to three K segments.  TS: k-steps a tile occupies in the stream
+// (more than the NK it reads when a pass leaves out the transient head's segment of the d(feat) tiles)
+template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int TS = NKA + NKB + NKC, int NA, int NB, int NC, int NOUT, class Ring>
 NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
                       const h8 (&inA)[NA][NCB][1], int ksA, const h8 (&inB)[NB][NCB][1], int ksB,
                       const h8 (&inC)[NC][NCB][1], int ksC,
@@ -263,9 +264,12 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         else if constexpr (k < NKA + NKB) return inB[ksB + k - NKA][cb][part];
         else return inC[ksC + k - NKA - NKB][cb][part];
     };
+    static_assert(NRT % 2 == 0, "the stream pairs the tiles of a group");
+    const char* wl = nullptr;
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        const char* wl = ring.consume();
+        constexpr int P0 = (i & 1) * TS;                 // k-step of this tile inside its two-tile chunk
+        if constexpr ((i & 1) == 0) wl = ring.consume();
         dg_zero<NCB>(acc[i & 1]);
         if (MASK) {      // the slot is recycled at the next consume(): take the masks now
             if constexpr ((i & 3) == 0) {
@@ -281,13 +285,15 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         }
         if constexpr (i > 0) {
             DgEpi<MASK, NOUT, NCB> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
-            nfl_tile<1, NCB, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
+            nfl_tile<1, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
             ring.note(2 * NCB);          // the epilogue's stash stores, issued at the tile's last k-step
         } else {
             NflNoEpi epi;
-            nfl_tile<1, NCB, NK, 0, h8>(acc[i & 1], wl, 0, getb, epi, ring);
+            nfl_tile<1, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
         }
-        ring.template pieces<NK, Ring::MAXP>();
+        // pieces the pair's k-loops did not get to (piece P0 + k is issued at k-step k of its tile)
+        if constexpr ((i & 1) == 0) ring.template pieces<NK, TS>();
+        else ring.template pieces<TS + NK, Ring::MAXP>();
     });
     DgEpi<MASK, NOUT, NCB> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
     last.all();
@@ -502,6 +508,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         if (A.rays_tiles) dg_pe_tile<4, 0, 8, NCB>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
         if (A.use_t)
             dg_tiles<WB, false, 8, 8, 8, 0, NCB>(ring, moff, Q, 0, Q, 8, Q, 0, P, 0, gst, NFL_GRD_FEAT);
+        else if (A.has_t)      // the stream's d(feat) tiles carry the transient segment too: read the first 8 k-steps of 16
+            dg_tiles<WB, false, 8, 8, 0, 0, NCB, 16>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_FEAT);
         else
             dg_tiles<WB, false, 8, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_FEAT);
         dg_tiles<WB, true, 8, 16, 1, 0, NCB>(ring, moff, P, 0, dS, 0, dS, 0, Q, 0, gst, NFL_GRD_D(8));
@@ -564,7 +572,7 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     A.has_t = hp->has_t;
     A.use_t = (hp->has_t && args->use_transient) ? 1 : 0;
     A.n_chunks = hp->n_chunks;
-    A.c_start = (hp->has_t && !A.use_t) ? 17 : 0;
+    A.c_start = (hp->has_t && !A.use_t) ? hp->n_chunks_sigma : 0;     // skip the transient head's chunks
     if (args->d_g_rays && (!A.rays_tiles || !args->d_rays || !args->d_z)) return NFL_EINVAL;
     A.spr = (args->n_samples + 31) / 32;
     A.nkp = hp->nkp;

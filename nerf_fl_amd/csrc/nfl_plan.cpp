@@ -45,11 +45,14 @@ struct Builder {
         s.nks = (int16_t)nks; s.kind = (int16_t)kind; s.col0 = (int16_t)col0; s.ncols = (int16_t)ncols;
         s.layer = (int16_t)layer;
     }
-    // one transposed (dgrad) tile in its own chunk: rows = columns [tcol0, tcol0+tncols) of the sources
+    // one transposed (dgrad) tile: rows = columns [tcol0, tcol0+tncols) of the sources.  `join`: append it to the chunk
+    // of the previous tile (the kernel walks its 4- and 8-tile groups two tiles per chunk: one barrier per pair)
     template <class SegFn>
-    void ttile(int tcol0, int tncols, int aux, SegFn segs) {
-        p->chunk_aux[p->n_chunks] = aux;
-        begin_chunk();
+    void ttile(int tcol0, int tncols, int aux, SegFn segs, bool join = false) {
+        if (!join) {
+            p->chunk_aux[p->n_chunks] = aux;
+            begin_chunk();
+        }
         NflRowTile& t = add_tile();
         t.trans = 1; t.tcol0 = (int16_t)tcol0; t.tncols = (int16_t)tncols;
         segs(t);
@@ -126,16 +129,17 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TSIGMA);
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_TRGB);
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TBETA);
-            });
+            }, t & 1);
         for (int j = 3; j >= 1; --j)
             for (int t = 0; t < 4; ++t)
                 b.ttile(32 * t, 32, nfl_msk_g(j) + t,
-                        [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0 + j); });
+                        [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0 + j); }, t & 1);
         b.ttile(W, d->n_tau, -1, [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0); });
     }
+    const int first_static_chunk = p->n_chunks;      // the backward of a pass without the transient head starts here
     for (int t = 0; t < 4; ++t)
         b.ttile(32 * t, 32, nfl_msk_dirh() + t,
-                [&](NflRowTile& r) { Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_RGB); });
+                [&](NflRowTile& r) { Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_RGB); }, t & 1);
     if (p->has_a)
         for (int t = 0; t < 2; ++t)
             b.ttile(W + cd + 32 * t, t == 0 ? 32 : p->n_a - 32, -1,
@@ -146,17 +150,17 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
         b.ttile(32 * t, 32, -1, [&](NflRowTile& r) {
             Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR);
             if (p->has_t) Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0);
-        });
+        }, t & 1);
     for (int t = 0; t < 8; ++t)
         b.ttile(32 * t, 32, nfl_msk_h(8) + t, [&](NflRowTile& r) {
             Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_FINAL);
             Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_SIGMA);
-        });
+        }, t & 1);
     const int npe = (cx + 31) / 32;         // 32-row tiles covering the encoded position
     for (int l = 8; l >= 2; --l) {          // layer l (1-based) transposed -> gradient of h_{l-1}
         for (int t = 0; t < 8; ++t)
             b.ttile((l == 5 ? cx : 0) + 32 * t, 32, nfl_msk_h(l - 1) + t,
-                    [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); });
+                    [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); }, t & 1);
         if (l == 5 && rays_grad)            // skip connection: rows that multiply the encoded position
             for (int t = 0; t < npe; ++t)
                 b.ttile(32 * t, cx - 32 * t < 32 ? cx - 32 * t : 32, -1,
@@ -168,7 +172,8 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
                     [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1); });
     p->reserved_flags = rays_grad ? 1 : 0;
     p->n_rt_sigma = p->n_rt_static = p->n_rt;
-    p->n_chunks_sigma = p->n_chunks_static = p->n_chunks;
+    p->n_chunks_static = p->n_chunks;
+    p->n_chunks_sigma = first_static_chunk;          // (field re-used by the dgrad stream)
     p->total_ks = b.ks_cursor;
     p->chunk_off[p->n_chunks] = p->total_ks * p->ks_bytes;
     p->stream_bytes = p->total_ks * p->ks_bytes;

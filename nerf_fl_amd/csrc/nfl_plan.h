@@ -61,13 +61,13 @@ struct NflRowTile {
 struct NflPlan {
     uint32_t magic;
     int32_t prec, nsplit;         // nsplit = 1 or 3 products; frags carry (nsplit==3 ? hi+lo : hi)
-    int32_t elem;                 // 0: fp16 fragments (forward stream), 1: bf16 fragments (dgrad stream)
+    int32_t elem;                 // 0: fp16 fragments (both streams now), 1: bf16 fragments
     int32_t is_bwd;               // 1: this is the dgrad (transposed) stream
     int32_t reserved_flags;       // dgrad stream: bit 0 = carries the tiles for the gradient w.r.t. the rays
     int32_t n_emb_xyz, nkp;       // nkp = ceil((6*n_emb_xyz+3)/16)
     int32_t has_a, has_t, n_a, n_tau;
     int32_t n_rt, n_rt_sigma, n_rt_static;
-    int32_t n_chunks, n_chunks_sigma, n_chunks_static;
+    int32_t n_chunks, n_chunks_sigma, n_chunks_static;   // dgrad stream: n_chunks_sigma = first chunk after the transient head's
     int32_t total_ks;             // k-steps in the whole stream
     int32_t ks_bytes;             // bytes per k-step: 1024 (hi) or 2048 (hi+lo)
     int32_t max_chunk_ks;         // largest chunk, in k-steps
@@ -77,8 +77,7 @@ struct NflPlan {
     float   beta_min;
     int32_t ld[19];               // in_features of each layer (row stride of its weight)
     int32_t chunk_off[NFL_MAX_CHUNKS + 1];   // byte offset of each chunk in the stream (+ end)
-    int32_t chunk_aux[NFL_MAX_CHUNKS + 1];   // dgrad: stash slot (k-step index inside a segment's activation record)
-                                             // whose 2 KiB is DMA'd beside the chunk as the relu mask; -1 = none
+    int32_t chunk_aux[NFL_MAX_CHUNKS + 1];   // dgrad: relu-mask word (nfl_msk_*) of the chunk's first tile; -1 = none
     NflRowTile rt[NFL_MAX_RT];
 };
 

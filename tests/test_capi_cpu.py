@@ -76,14 +76,17 @@ def test_bwd_plan_structure(L):
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
     assert hdr[1] == 1 and hdr[2] == 1 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == 0     # fp16 single-product fragments, dgrad stream, no rays-gradient tiles
     n_rt, n_chunks, total_ks = hdr[12], hdr[15], hdr[18]
-    # one transposed row tile per chunk: transient 4+12+1, rgb^T 4, appearance rows 2, feat 8, h8 8, 7 trunk layers x 8
-    assert n_rt == n_chunks == 17 + 4 + 2 + 8 + 8 + 56
+    # transposed row tiles: transient 4+12+1, rgb^T 4, appearance rows 2, feat 8, h8 8, 7 trunk layers x 8; the tiles of
+    # the 4- and 8-tile groups travel two per chunk, the latent rows one per chunk
+    assert n_rt == 17 + 4 + 2 + 8 + 8 + 56
+    assert n_chunks == (2 + 6 + 1) + 2 + 2 + 4 + 4 + 28
+    assert hdr[16] == 9                                     # first chunk of the non-transient part (n_chunks_sigma re-used)
     assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 16 + 8 * 17 + 56 * 16
     assert L.nfl_bwd_packed_bytes(C.byref(d), 0) == total_ks * 1024 + n_rt * 128
     # with the gradient w.r.t. the rays: + direction rows (1 tile, 8 ks) + encoded-position rows of layers 5 and 1 (2 x 2 tiles, 16 ks)
     assert L.nfl_bwd_plan_build(C.byref(d), 1, buf, n) == 0
     hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)
-    assert hdr2[5] == 1 and hdr2[12] == n_rt + 5 and hdr2[18] == total_ks + 8 + 4 * 16
+    assert hdr2[5] == 1 and hdr2[12] == n_rt + 5 and hdr2[15] == n_chunks + 5 and hdr2[18] == total_ks + 8 + 4 * 16
     # stash sizes: per 32-sample segment 194 / 189 KiB (+ 4 KiB tail pad), then 84 relu-mask words x 256 B per segment
     assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 194 * 1024 + 4096 + 8 * 4 * 84 * 256
     assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == (8 * 4 + 1) * 189 * 1024 + 4096
