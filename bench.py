@@ -216,7 +216,7 @@ def main():
         # separate passes, so it cannot be measured inside this process
         traffic = None
         try:
-            summ = json.load(open(os.path.join(ROOT, "profiles", "r01f_summary.json")))
+            summ = json.load(open(os.path.join(ROOT, "profiles", "r01g_summary.json")))
             for k, v in summ["traffic"].items():
                 if kname.split("(")[0] in k:
                     traffic = v["hbm_bytes_max_launch"]
