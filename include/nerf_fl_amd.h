@@ -139,8 +139,8 @@ typedef struct nfl_pass_args {
     float* d_depth_transient_only;/* (R)  depth_fine_transient                           */
     float* d_field_raw;         /* (R*n_samples,9) per-sample field outputs [rgb,sigma,rgb_t,sigma_t,beta] or NULL;
                                    required (with d_act_stash) when a backward will follow                      */
-    char*  d_act_stash;         /* nfl_act_stash_bytes(): bf16 layer inputs of every sample, MFMA fragment order,
-                                   consumed by nfl_render_backward; NULL for inference                          */
+    char*  d_act_stash;         /* nfl_act_stash_bytes(): fp16 layer inputs of every sample in MFMA fragment order, then
+                                   the relu-mask words; consumed by nfl_mlp_dgrad / nfl_mlp_wgrad; NULL for inference */
     /* BARF coarse-to-fine encoding (reference BarfPosEmbedding, nerf.py:35-77): per-frequency weights,
        computed by the caller exactly as barf_weight(freq, epoch) does; NULL = plain PosEmbedding     */
     const float* d_pe_w_xyz;    /* (n_emb_xyz) or NULL                                                   */
