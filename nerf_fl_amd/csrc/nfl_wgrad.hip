@@ -462,13 +462,28 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     for (int j = 0; j < nj; ++j) total_cost += hp->cost[j];
     const int budget = ncu;     // one resident workgroup per CU: a second round only repeats the pipeline fill / drain
                                 // (measured 1.06 / 1.14 / 1.23 / 1.32 ms for 1 / 2 / 3 / 4 workgroups per CU)
-    int acc_wg = 0;
+    // proportional shares rounded down, then the workgroups left over go one at a time to the job whose workgroups
+    // carry the most bytes each (every CU gets a workgroup and the slowest job sets the kernel's time)
+    int n_wg[WG_MAX_JOBS], used = 0;
     for (int j = 0; j < nj; ++j) {
         int n = (int)((long long)budget * hp->cost[j] / total_cost);
         if (n < 1) n = 1;
         if (n > A.n_seg) n = A.n_seg;
+        n_wg[j] = n;
+        used += n;
+    }
+    while (used < budget) {
+        int best = -1;
+        for (int j = 0; j < nj; ++j)
+            if (n_wg[j] < A.n_seg && (best < 0 || (long long)hp->cost[j] * n_wg[best] > (long long)hp->cost[best] * n_wg[j])) best = j;
+        if (best < 0) break;
+        n_wg[best]++;
+        used++;
+    }
+    int acc_wg = 0;
+    for (int j = 0; j < nj; ++j) {
         A.wg_start[j] = acc_wg;
-        acc_wg += n;
+        acc_wg += n_wg[j];
     }
     A.wg_start[nj] = acc_wg;
     static bool attr_set = false;
