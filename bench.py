@@ -11,48 +11,95 @@ resident in HBM.
                 + hand-written backward + gradient all-reduce (N > 1) + Adam step
                 (lr 5e-4, eps 1e-8: utils/__init__.py:30-32) + weight re-pack
   --mode render one step = render_rays forward only (pack + coarse + sample_pdf + fine)
+  --workload cfg3   configs[3] per-GPU shape instead (Phototourism: NeRF-W a+t, N_vocab 1500, black background,
+                    per-ray near/far; --rays 1024 is the README batch)
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--mode train|render]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rays shard across ranks with no data-path collective (weak scaling: every rank
-renders its own 4096-ray batch); training adds ONE flat RCCL all-reduce of the
-gradients per step.  Prints ONE JSON line on rank 0.
+N > 1: run plainly (`python bench.py --gpus N`), this process then starts N ranks itself -- one fresh process per
+GPU, rendezvous on 127.0.0.1, and exits non-zero if any rank fails -- or run under a launcher
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`), which is detected by WORLD_SIZE.
+Rays shard across ranks with no data-path collective (weak scaling: every rank renders its own batch);
+training adds ONE flat RCCL all-reduce of the gradients per step.  Rank 0 prints ONE JSON line; `n_gpus` in
+it is the size of the process group that actually ran.
+
+  --dry   rehearsal of the multi-rank plumbing without a GPU: gloo, CPU tensors, the same launcher, the same flat
+          gradient all-reduce over stand-in parameters (tests/test_bench_launcher.py)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-R_PER_GPU = 4096
 N_SAMPLES, N_IMPORTANCE = 64, 64
 # algorithmic FLOPs (2 x weight-matrix MACs) per field evaluation, SURVEY.md section 8(d)
-FLOP_BASE_EVAL = 2 * 593408
+FLOP_EVAL = {"base": 2 * 593408, "at": 2 * 684160}
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02_summary.json")
 
 
-def build_models(dev):
-    from nerf_fl_amd import NeRF, PosEmbedding
-    from oracle import nerfw_oracle as orc     # only for the seeded weights / rays (shared with the tests)
-    spec = orc.FieldSpec("coarse")
-    models = {}
-    for typ, seed in (("coarse", 11), ("fine", 12)):
-        m = NeRF(typ)
-        m.load_state_dict(orc.make_field_params(orc.FieldSpec(typ), seed, "sharp"))
-        models[typ] = m.to(dev)
-    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
-    return models, emb, spec
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--mode", default="train", choices=["train", "render"])
+    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg3"])
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU and step")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
+    ap.add_argument("--graph", action="store_true", help="train mode: replay the step from one captured HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry", action="store_true")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(n_rays=4096, reps=3):
-    """The oracle (CPU restatement of the reference, eager PyTorch fp32) on the host cores.
-    A 1-GPU box gives this job a 16-CPU share; more threads than that only oversubscribe."""
+# ------------------------------------------------------------------------------------------------
+# launcher (parent process; never touches the GPU)
+# ------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    """Start args.gpus fresh ranks of this script, one per device; return the worst exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   NFL_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc, deadline = 0, None
+    pending = set(range(args.gpus))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                rc = rc or code
+                print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                if deadline is None:
+                    deadline = time.time() + 20        # the others are stuck in a collective: do not wait for ever
+        if deadline is not None and time.time() > deadline:
+            for r in pending:
+                procs[r].kill()                          # exact PIDs this process started
+        time.sleep(0.05)
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle = CPU restatement of the reference, eager PyTorch fp32, host cores)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(mode, n_rays=4096):
+    """Forward (best of 3) and, in train mode, one full train step (forward + NerfWLoss + backward through autograd,
+    1 repetition) of configs[1] on the host cores.  A 1-GPU box gives this job a 16-CPU share."""
+    import torch
     from oracle import nerfw_oracle as orc
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     torch.manual_seed(0)
@@ -62,33 +109,98 @@ def cpu_baseline(n_rays=4096, reps=3):
     kw = dict(n_samples=N_SAMPLES, n_importance=N_IMPORTANCE, perturb=1.0, noise_std=1.0, white_back=True,
               perturb_rand=torch.rand(n_rays, N_SAMPLES), noise_coarse=torch.randn(n_rays, N_SAMPLES),
               u=torch.rand(n_rays, N_IMPORTANCE), noise_fine=torch.randn(n_rays, N_SAMPLES + N_IMPORTANCE))
+    units = n_rays * (N_SAMPLES + N_IMPORTANCE)
     best = float("inf")
     with torch.no_grad():
-        for _ in range(reps):
+        for _ in range(3):
             t0 = time.perf_counter()
             orc.render_rays(spec_c, P_c, spec_f, P_f, rays, **kw)
             best = min(best, time.perf_counter() - t0)
-    return {"value": n_rays * (N_SAMPLES + N_IMPORTANCE) / best, "unit": "ray-samples/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays} rays x (64+64), base NeRF coarse+fine, forward render_rays, best of {reps} "
-                      f"({best:.2f} s each); oracle/nerfw_oracle.py"}
+    out = {"value": units / best, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": f"{n_rays} rays x (64+64), base NeRF coarse+fine, forward render_rays, best of 3 "
+                     f"({best:.2f} s each); oracle/nerfw_oracle.py"}
+    if mode == "train":
+        for P in (P_c, P_f):
+            for p in P.values():
+                p.requires_grad_(True)
+        target = torch.rand(n_rays, 3)
+        t0 = time.perf_counter()
+        res = orc.render_rays(spec_c, P_c, spec_f, P_f, rays, **kw)
+        sum(orc.nerfw_loss(res, target).values()).backward()
+        dt = time.perf_counter() - t0
+        out = {"value": units / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"{n_rays} rays x (64+64), base NeRF coarse+fine, one train step = forward render_rays + "
+                         f"NerfWLoss + autograd backward (no optimizer), 1 repetition ({dt:.2f} s); "
+                         "oracle/nerfw_oracle.py",
+               "forward_value": out["value"], "forward_sample": out["sample"]}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--mode", default="train", choices=["train", "render"])
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+# ------------------------------------------------------------------------------------------------
+# one rank
+# ------------------------------------------------------------------------------------------------
+def build_models(dev, workload):
+    import torch
+    from nerf_fl_amd import NeRF, PosEmbedding, synth
+    at = workload == "cfg3"
+    models = {}
+    for typ, seed in (("coarse", 11), ("fine", 12)):
+        fine_kw = dict(encode_appearance=at, encode_transient=at) if typ == "fine" else {}
+        m = NeRF(typ, beta_min=0.03, **fine_kw)
+        m.load_state_dict(synth.make_field_params(seed, "sharp", typ=typ, **fine_kw))
+        models[typ] = m.to(dev)
+    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
+    if at:
+        torch.manual_seed(5)
+        emb["a"] = torch.nn.Embedding(1500, 48).to(dev)
+        emb["t"] = torch.nn.Embedding(1500, 16).to(dev)
+    return models, emb
 
+
+def run_dry(args, rank, world):
+    """gloo rehearsal: process group, the flat gradient all-reduce over stand-in parameters, barrier + MAX timing."""
+    import torch
+    import torch.distributed as dist
+    from nerf_fl_amd import parallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if os.environ.get("NFL_BENCH_FAIL_RANK") == str(rank):
+        os._exit(3)                                            # failure injection for the launcher test
+    torch.manual_seed(rank)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (595844, 595844, 1500 * 64)]
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for p in params:
+            p.grad = torch.full_like(p, float(rank + 1))
+        parallel.all_reduce_gradients(params)
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    expect = sum(range(1, world + 1)) / world
+    ok = all(bool((p.grad == expect).all()) for p in params)
+    if rank == 0:
+        print(json.dumps({"metric": "ray-samples/sec (64+64)", "value": None, "unit": "ray-samples/s",
+                          "n_gpus": dist.get_world_size(), "ranks": dist.get_world_size(), "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": 1e3 * float(t.item()) / max(args.steps, 1), "dry": True,
+                          "backend": "gloo", "allreduce_ok": ok, "data": "synthetic"}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 4
+
+
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has WORLD_SIZE={world}; "
+                         "refusing to report a number for a different GPU count than asked")
+    if args.dry:
+        return run_dry(args, rank, world)
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -104,37 +216,43 @@ def main():
     torch.cuda.set_device(dev)
 
     import nerf_fl_amd
-    from nerf_fl_amd import render_rays
+    from nerf_fl_amd import parallel, render_rays, synth
     from nerf_fl_amd import rendering as rnd
-    from oracle import nerfw_oracle as orc
+    from nerf_fl_amd.train import Adam, GraphedTrainStep, NerfWLoss
     nerf_fl_amd.set_precision(args.precision)
 
-    models, emb, _ = build_models(dev)
+    R = args.rays
+    cfg3 = args.workload == "cfg3"
+    white_back = not cfg3
+    models, emb = build_models(dev, args.workload)
     torch.manual_seed(1234 + rank)
-    rays = orc.make_rays(R_PER_GPU, 100 + rank).to(dev)       # each rank: its own shard of rays
-    ts = torch.zeros(R_PER_GPU, dtype=torch.long, device=dev)
-
-    target = torch.rand(R_PER_GPU, 3, device=dev)
-    params = [p for m in models.values() for p in m.parameters()]
-    from nerf_fl_amd.train import Adam, NerfWLoss   # torch.optim.Adam's arithmetic in one launch (C ABI nfl_adam_step)
+    rays = (synth.make_rays_photo if cfg3 else synth.make_rays)(R, 100 + rank).to(dev)   # each rank: its own shard
+    ts = torch.randint(0, 1500, (R,), device=dev) if cfg3 else torch.zeros(R, dtype=torch.long, device=dev)
+    target = torch.rand(R, 3, device=dev)
+    modules = list(models.values()) + [emb[k] for k in ("a", "t") if k in emb]
+    params = [p for m in modules for p in m.parameters()]
     loss_fn = NerfWLoss()
-    opt = Adam(params, lr=5e-4, eps=1e-8)
-    from nerf_fl_amd import parallel
+    opt = Adam(params, lr=5e-4, eps=1e-8, capturable=args.graph)
 
     def render_step():
         with torch.no_grad():
-            return render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, True, False)
+            return render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False)
 
     def train_step():
         opt.zero_grad(set_to_none=True)
-        res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, True, False)
-        loss = sum(loss_fn(res, target).values())      # c_l + f_l (losses.py:35-41), forward and backward one launch each
+        res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False)
+        loss = sum(loss_fn(res, target).values())      # c_l + f_l (+ b_l + s_l), forward and backward one launch each
         loss.backward()
         if dist is not None:
             parallel.all_reduce_gradients(params)
         opt.step()
 
-    step = train_step if args.mode == "train" else render_step
+    if args.mode == "train" and args.graph:
+        graphed = GraphedTrainStep(models, emb, params, opt, loss_fn, rays, ts, target, N_SAMPLES, N_IMPORTANCE,
+                                   white_back=white_back, all_reduce=dist is not None)
+        step = graphed.replay
+    else:
+        step = train_step if args.mode == "train" else render_step
 
     def sync():
         torch.cuda.synchronize()
@@ -155,27 +273,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_units = R_PER_GPU * (N_SAMPLES + N_IMPORTANCE) * world * args.steps
+    n_ranks = dist.get_world_size() if dist is not None else 1
+    F = N_SAMPLES + N_IMPORTANCE
+    total_units = R * F * n_ranks * args.steps
+    fine_kind = "at" if cfg3 else "base"
+    wl = ("configs[3] per-GPU shape: phototourism-like rays (per-ray near/far), NeRF-W a+t fine field, N_vocab 1500, "
+          "black background" if cfg3 else
+          "configs[1]: lego-like rays, base NeRF coarse+fine, white_back")
     out = {
         "metric": "ray-samples/sec (64+64)",
         "value": total_units / elapsed,
         "unit": "ray-samples/s",
-        "n_gpus": world,
+        "n_gpus": n_ranks,
+        "ranks": n_ranks,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f16x3" if args.precision == "f16x3" else "f16",
+        "dtype": ("f16x3 fwd + f16 bwd" if args.mode == "train" else "f16x3") if args.precision == "f16x3" else "f16",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: lego-like rays 4096/GPU, N_samples=64 + N_importance=64, base NeRF "
-                               "coarse+fine, perturb=1 noise_std=1 white_back; "
-                               + ("train step: render_rays fwd + colour loss + HIP backward + grad all-reduce + Adam"
+        "config": {"workload": f"{wl}; {R} rays/GPU, N_samples=64 + N_importance=64, perturb=1 noise_std=1; "
+                               + ("train step: render_rays fwd + NerfWLoss + HIP backward + grad all-reduce + Adam + re-pack"
+                                  + (", replayed from one HIP graph" if args.graph else "")
                                   if args.mode == "train" else
                                   "forward render_rays (pack + coarse pass + sample_pdf + fine pass)"),
-                   "rays_per_gpu": R_PER_GPU, "mode": args.mode, "precision": args.precision,
-                   "mlp_evals_per_ray": N_SAMPLES + N_SAMPLES + N_IMPORTANCE},
+                   "rays_per_gpu": R, "mode": args.mode, "precision": args.precision,
+                   "forward_arithmetic": "fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate (f16x3)"
+                                         if args.precision == "f16x3" else "fp16 MFMA, 1 product, fp32 accumulate",
+                   "backward_arithmetic": "fp16 MFMA, 1 product, fp32 accumulate, fp16 activation/gradient stashes "
+                                          "under a device-chosen power-of-two loss scale; gradients returned in fp32",
+                   "mlp_evals_per_ray": N_SAMPLES + F, "hip_graph": bool(args.graph)},
     }
 
     if args.mode == "train":
@@ -187,52 +316,94 @@ def main():
         for _ in range(20):
             render_step()
         sync()
-        out["render_only_value"] = R_PER_GPU * (N_SAMPLES + N_IMPORTANCE) * world * 20 / (time.perf_counter() - t0)
+        out["render_only_value"] = R * F * n_ranks * 20 / (time.perf_counter() - t0)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: the fine-pass launch of nfl_render_kernel
-        # (4096 rays x 128 samples x 1.1868 MFLOP), timed alone with events on the launch stream
-        f_f = rnd._field(models["fine"], 10, 4, dev)
-        F = N_SAMPLES + N_IMPORTANCE
-        z = torch.sort(2 + 4 * torch.rand(R_PER_GPU, F, device=dev), dim=1)[0]
-        noise = torch.randn(R_PER_GPU, F, device=dev)
+        out.update(roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back))
+        if n_ranks == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.mode)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back):
+    """Roofline of the dominant kernel: the fine-pass launch of nfl_render_kernel (R rays x 128 samples), timed
+    alone with events on the launch stream, in the instantiation the timed mode runs (MODE 1 = training forward,
+    writes the activation stash; MODE 0 = inference) and, beside it, in the other one."""
+    import torch
+    from nerf_fl_amd import _lib
+    R = rays.shape[0]
+    F = N_SAMPLES + N_IMPORTANCE
+    f_f = rnd._field(models["fine"], 10, 4, dev)
+    z = torch.sort(rays[:, 6:7] + (rays[:, 7:8] - rays[:, 6:7]) * torch.rand(R, F, device=dev), dim=1)[0]
+    noise = torch.randn(R, F, device=dev)
+    lat = {}
+    if fine_kind == "at":
+        lat = dict(a_emb=emb["a"](ts).detach(), t_emb=emb["t"](ts).detach())
+    flops = R * F * FLOP_EVAL[fine_kind]
+
+    def time_pass(stash):
+        run = lambda: rnd._run_pass(f_f, rays, F, z=z, noise=None if lat else noise, noise_std=1.0,
+                                    white_back=white_back, stash=stash, **lat)
         for _ in range(5):
-            rnd._run_pass(f_f, rays, F, z=z, noise=noise, noise_std=1.0, white_back=True)
+            run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 30
         torch.cuda.synchronize()
         e0.record()
         for _ in range(reps):
-            rnd._run_pass(f_f, rays, F, z=z, noise=noise, noise_std=1.0, white_back=True)
+            run()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        flops = R_PER_GPU * F * FLOP_BASE_EVAL
-        achieved = flops / (ms * 1e-3) / 1e12
-        from nerf_fl_amd import _lib
-        kname = _lib.lib().nfl_render_kernel_name(rnd._PREC[args.precision], 10).decode()
-        # HBM bytes per launch of this kernel from the committed PMC profile (FETCH_SIZE doubled as the
-        # gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); collected by rocprofv3 --pmc in
-        # separate passes, so it cannot be measured inside this process
-        traffic = None
-        try:
-            summ = json.load(open(os.path.join(ROOT, "profiles", "r01g_summary.json")))
-            for k, v in summ["traffic"].items():
-                if kname.split("(")[0] in k:
-                    traffic = v["hbm_bytes_max_launch"]
-        except Exception:
-            pass
-        out["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": achieved / PEAK_F16_MFMA_TFLOPS, "traffic": traffic,
-                           "kernel": kname, "launch_ms": ms,
-                           "note": "algorithmic FLOPs (2 x 593408 MAC per field evaluation x 4096 rays x 128 samples); "
-                                   "f16x3 issues 3 MFMA products per algorithmic product"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        return e0.elapsed_time(e1) / reps
+
+    base = _lib.lib().nfl_render_kernel_name(rnd._PREC[args.precision], 10).decode()      # "...<3, 1, 10, 0>"
+    names = {False: base, True: base[:-2] + "1>"}
+    # HBM bytes per launch from the committed PMC profile (FETCH_SIZE doubled as the gfx950 note in
+    # MI355X_MICROARCH.md prescribes, + WRITE_SIZE); collected by rocprofv3 --pmc in separate passes, so it cannot be
+    # measured inside this process
+    summ = {}
+    try:
+        summ = json.load(open(PROFILE_SUMMARY))
+    except Exception:
+        pass
+
+    def traffic_of(kname):
+        for k, v in summ.get("traffic", {}).items():
+            if kname.split("(")[0] in k:
+                return v.get("hbm_bytes_max_launch")
+        return None
+
+    def entry(stash):
+        ms = time_pass(stash)
+        ach = flops / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": traffic_of(names[stash]), "kernel": names[stash],
+                "launch_ms": ms,
+                "note": f"algorithmic FLOPs ({FLOP_EVAL[fine_kind]} per field evaluation x {R} rays x {F} samples); "
+                        "f16x3 issues 3 MFMA products per algorithmic product"}
+
+    train = args.mode == "train" and args.precision == "f16x3"
+    out = {"roofline": entry(train)}
+    if args.precision == "f16x3":
+        out["roofline_inference" if train else "roofline_training"] = entry(not train)
+    st = summ.get("step_traffic")
+    if st and args.mode == "train":
+        out["step_traffic"] = st       # PMC HBM bytes of one whole train step vs its algorithmic bytes (profiles/)
+    return out
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    sys.exit(run_rank(args))
 
 
 if __name__ == "__main__":

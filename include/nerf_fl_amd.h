@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NFL_ABI_VERSION 4
+#define NFL_ABI_VERSION 5
 #define NFL_GMAX_SLOTS 1024
 
 enum {
@@ -41,6 +41,8 @@ enum {
 
 /* Arithmetic used inside the MLP (everything outside the matrix products --
  * positional encoding, activations, compositing, sampling -- is always fp32). */
+#define NFL_STATUS_NONFINITE 1
+
 enum {
     NFL_PREC_F16X3 = 0,   /* fp16 MFMA, operands split hi+lo, 3 products: ~2^-21 relative, fp32-class (default) */
     NFL_PREC_F16   = 1    /* fp16 MFMA, single product: ~2^-11 relative (fast mode)                               */
@@ -145,6 +147,12 @@ typedef struct nfl_pass_args {
        computed by the caller exactly as barf_weight(freq, epoch) does; NULL = plain PosEmbedding     */
     const float* d_pe_w_xyz;    /* (n_emb_xyz) or NULL                                                   */
     const float* d_pe_w_dir;    /* (n_emb_dir) or NULL                                                   */
+    /* optional status word (device, int32, never cleared by the library): bit NFL_STATUS_NONFINITE is OR-ed in when a
+       composited per-ray output of this pass is not finite.  The MLP multiplies fp16 operands: an activation or a
+       weight beyond fp16's range (|x| > 65504), which the fp32 reference would carry, turns into NaN here (hi = inf,
+       lo = -inf) and poisons its ray -- the ABI's range limit; this word is how a caller detects it
+       without scanning the outputs. */
+    int32_t* d_status;
     /* used by nfl_field_forward only (leave NULL / 0 otherwise) */
     const float* d_embedded;
     int32_t n_points, embedded_stride;
@@ -262,6 +270,12 @@ typedef struct nfl_adam_tensors {
 } nfl_adam_tensors;
 int nfl_adam_step(const nfl_adam_tensors* tensors, int32_t n_tensors, float lr, float beta1, float beta2, float eps,
                   int32_t step, void* stream);
+/* The same update with its scalars in DEVICE memory, for launches captured in a HIP graph (a captured launch freezes
+ * by-value arguments): d_hyper = float[4] {lr, beta1, beta2, eps}; *d_step = number of updates already applied to
+ * these tensors (the kernel uses *d_step + 1).  bump != 0: a second, one-thread launch then increments *d_step; pass 0
+ * for all but the last call when more than NFL_ADAM_MAX_TENSORS tensors share one counter. */
+int nfl_adam_step_dev(const nfl_adam_tensors* tensors, int32_t n_tensors, const float* d_hyper, int32_t* d_step,
+                      int32_t bump, void* stream);
 
 /* ---- NerfWLoss (reference losses.py:35-50) on the renderer's outputs, forward and backward in one launch each.
  * Terms (d_losses[4], zeroed by nfl_loss_forward): c_l, f_l, b_l, s_l; f_l uses beta when d_beta != NULL

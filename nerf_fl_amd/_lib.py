@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFL_LIB") or os.path.join(_HERE, "libnerf_fl_amd.so")
 
-NFL_ABI_VERSION = 4
+NFL_ABI_VERSION = 5
 NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
@@ -55,7 +55,7 @@ class PassArgs(C.Structure):
         ("d_rgb_static_only", C.c_void_p), ("d_depth_static_only", C.c_void_p),
         ("d_rgb_transient_only", C.c_void_p), ("d_depth_transient_only", C.c_void_p),
         ("d_field_raw", C.c_void_p), ("d_act_stash", C.c_void_p),
-        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p),
+        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p), ("d_status", C.c_void_p),
         ("d_embedded", C.c_void_p), ("n_points", C.c_int32), ("embedded_stride", C.c_int32),
     ]
 
@@ -129,6 +129,7 @@ SYMBOLS = [
                                 C.POINTER(FieldGrads), C.c_void_p]),
     ("nfl_adam_step", C.c_int, [C.POINTER(AdamTensors), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 C.c_void_p]),
+    ("nfl_adam_step_dev", C.c_int, [C.POINTER(AdamTensors), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     ("nfl_loss_forward", C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     ("nfl_loss_backward", C.c_int, [C.POINTER(LossArgs), C.c_void_p]),
     ("nfl_abi_version", C.c_int, []),

@@ -45,6 +45,45 @@ extern "C" int nfl_adam_step(const nfl_adam_tensors* t, int32_t n_tensors, float
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }
 
+// Graph-capturable form: learning rate, betas, eps and the step count are read from device memory by the kernel, so
+// one captured launch stays valid while a scheduler changes the rate and the count advances with every replay.
+__global__ __launch_bounds__(256) void nfl_adam_dev_kernel(const nfl_adam_tensors T, const float* __restrict__ hyper,
+                                                           const int32_t* __restrict__ d_step) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3];
+    const int step = *d_step + 1;
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    const float one_minus_b1 = 1.0f - b1, one_minus_b2 = 1.0f - b2;
+    const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const int t = blockIdx.y;
+    const float* g = T.grad[t];
+    if (g == nullptr) return;
+    float* p = T.param[t];
+    float* m = T.exp_avg[t];
+    float* v = T.exp_avg_sq[t];
+    const int n = T.numel[t];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * one_minus_b1;
+        const float vi = v[i] * b2 + one_minus_b2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+    }
+}
+__global__ void nfl_adam_bump_kernel(int32_t* d_step) { *d_step += 1; }
+
+extern "C" int nfl_adam_step_dev(const nfl_adam_tensors* t, int32_t n_tensors, const float* d_hyper, int32_t* d_step,
+                                 int32_t bump, void* stream) {
+    if (!t || n_tensors < 0 || n_tensors > NFL_ADAM_MAX_TENSORS || !d_hyper || !d_step) return NFL_EINVAL;
+    if (n_tensors == 0) return NFL_OK;
+    for (int i = 0; i < n_tensors; ++i)
+        if (t->numel[i] < 0 || (t->numel[i] > 0 && (!t->param[i] || !t->exp_avg[i] || !t->exp_avg_sq[i]))) return NFL_EINVAL;
+    hipLaunchKernelGGL(nfl_adam_dev_kernel, dim3(32, n_tensors), dim3(256), 0, static_cast<hipStream_t>(stream), *t, d_hyper,
+                       d_step);
+    if (bump) hipLaunchKernelGGL(nfl_adam_bump_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), d_step);
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // NerfWLoss (reference losses.py:35-50) in two launches instead of ~8 + ~8 small ATen kernels:
 //   c_l = coef 0.5 mean((rgb_coarse - t)^2)

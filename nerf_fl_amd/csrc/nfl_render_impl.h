@@ -1010,6 +1010,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             if (q == SPR - 1) {
                 // ray complete: lane k holds the composited quantity k
                 const float wsum = __shfl(acc, 3);
+                if (a.d_status) {       // fp16 operand range exceeded somewhere on this ray (header: d_status)
+                    const bool bad = lane < NFL_NST && !(fabsf(acc) <= 3.0e38f);
+                    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.d_status, NFL_STATUS_NONFINITE);
+                }
                 const float white = a.white_back ? 1.f - wsum : 0.f;
                 const float stat = acc + white;                  // meaningful on lanes 4..6 and 12..14
                 const float tran = __shfl(acc, (lane + 3) & 63); // lanes 4..6 read 7..9

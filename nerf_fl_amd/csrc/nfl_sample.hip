@@ -5,6 +5,11 @@
 // depths and per-row sort).  Per ray: ~30 small ATen kernels become one wave doing
 //   1. w = weights[1:-1] + 1e-5, wave reduction for the sum, pdf = w / sum
 //   2. cdf = [0, inclusive wavefront prefix scan of pdf]      (shuffle scan, 64 bins per pass)
+//      Both the sum and the scan accumulate in fp64 and round to fp32 once per output.  For the scan that is
+//      exactly what the reference computes on the CPU (ATen's cumsum accumulates fp32 inputs in double), and because
+//      the pdf entries lie in [2^-23, 1] every fp64 partial sum is exact, so the parallel scan order cannot show: the
+//      cdf is bit-identical to torch.cumsum's for the same pdf.  torch.sum's fp32 result depends on the host's vector
+//      width; the correctly rounded sum used here is within an ulp or two of any of them.
 //   3. for every u: count of cdf <= u by binary search in LDS (searchsorted right=True),
 //      clamp, gather, lerp; zero-width bins (< eps) get denominator 1
 //   4. merge with the coarse depths by rank counting in LDS (stable; the result is the
@@ -35,26 +40,26 @@ __global__ __launch_bounds__(256) void nfl_sample_pdf_kernel(SampleArgs a) {
     const float* wr = a.w + (size_t)ray * S + 1;
     const float eps = 1e-5f;
 
-    // 1. sum of (w + eps)
-    float part = 0.f;
-    for (int j = lane; j < M; j += 64) part += wr[j] + eps;
+    // 1. sum of (w + eps): fp32 addends (as the reference forms them), fp64 accumulation, one rounding
+    double part = 0.0;
+    for (int j = lane; j < M; j += 64) part += (double)(wr[j] + eps);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
-    const float total = part;
+    const float total = (float)part;
 
-    // 2. cdf by wavefront inclusive scan, 64 bins per pass
-    float run = 0.f;
+    // 2. cdf by wavefront inclusive scan, 64 bins per pass (fp64 partial sums, see the header)
+    double run = 0.0;
     if (lane == 0) cdf[0] = 0.f;
     for (int j0 = 0; j0 < M; j0 += 64) {
         const int j = j0 + lane;
-        float v = j < M ? (wr[j] + eps) / total : 0.f;
+        double v = j < M ? (double)((wr[j] + eps) / total) : 0.0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const float n = __shfl_up(v, d);
+            const double n = __shfl_up(v, d);
             if (lane >= d) v += n;
         }
         v += run;
-        if (j < M) cdf[j + 1] = v;
+        if (j < M) cdf[j + 1] = (float)v;
         run = __shfl(v, 63);
     }
     for (int j = lane; j < NB; j += 64) bins[j] = 0.5f * (zr[j] + zr[j + 1]);

@@ -18,6 +18,11 @@ even when noise_std == 0), rand (importance u), randn_like (fine noise) in that
 order.  The same draws are made here with torch's
 generator on the rays' device, unless the caller injects them through the
 build-defined kwargs `perturb_rand`, `noise_coarse`, `u`, `noise_fine`.
+
+Numerical range: the fused MLP multiplies fp16 operands (split hi+lo), so activations and weights must stay
+within fp16's range (|x| <= 65504); beyond it the affected rays come out as NaN where the fp32 reference stays
+finite.  Every pass records that in a device status word; `check_status()` (or the build-defined kwarg
+`check_finite=True`) turns it into a FloatingPointError.
 """
 import ctypes as C
 import os
@@ -27,7 +32,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["render_rays", "set_precision", "get_precision"]
+__all__ = ["render_rays", "set_precision", "get_precision", "check_status"]
 
 _PREC = {"f16x3": _lib.NFL_PREC_F16X3, "f16": _lib.NFL_PREC_F16}
 _precision = os.environ.get("NERF_FL_AMD_PREC", "f16x3")
@@ -47,6 +52,33 @@ def get_precision():
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+_status_words = {}
+
+
+def _status_word(dev):
+    """One int32 per device that every render pass ORs NFL_STATUS_* bits into (include/nerf_fl_amd.h: d_status)."""
+    k = str(dev)
+    if k not in _status_words:
+        _status_words[k] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _status_words[k]
+
+
+def check_status(device=None):
+    """Synchronise and raise FloatingPointError if a render pass since the last check produced a non-finite
+    per-ray output: the MLP runs on fp16 operands, so an activation or weight beyond |x| = 65504 (which the fp32
+    reference would carry) becomes NaN here -- the documented range limit of this build.
+    The status word is cleared."""
+    for k, w in list(_status_words.items()):
+        if device is not None and k != str(torch.device(device)):
+            continue
+        bits = int(w.item())
+        if bits:
+            w.zero_()
+            raise FloatingPointError(
+                f"nerf_fl_amd: a render pass on {k} produced non-finite outputs: an activation or weight exceeded "
+                "fp16's range (|x| > 65504) inside the fused MLP (see INTEGRATION.md, 'Numerical range')")
 
 
 def _stream():
@@ -87,7 +119,7 @@ class _PackedField:
         self.packed_bytes = L.nfl_packed_bytes(C.byref(self.desc), prec)
         self.packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=device)
         self.key = None
-        # dgrad stream (transposed weights, bf16 hi+lo); built lazily on the first training forward
+        # dgrad stream (transposed weights, fp16, one product); built lazily on the first training forward
         self.bplans = {}          # rays_grad -> dict(h, d, packed, nbytes, key)
         self.wplans = {}          # use_transient -> (host blob, device copy) of the wgrad job list
 
@@ -110,7 +142,7 @@ class _PackedField:
         return out
 
     def ensure_bwd_packed(self, rays_grad=False):
-        """dgrad stream (transposed weights, bf16 hi+lo) for the current parameters."""
+        """dgrad stream (transposed weights, fp16) for the current parameters."""
         L = _lib.lib()
         rg = int(bool(rays_grad))
         if rg not in self.bplans:
@@ -271,6 +303,7 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     a.d_field_raw = _ptr(out.get("field_raw"))
     a.d_act_stash = _ptr(out.get("act_stash"))
     a.d_pe_w_xyz, a.d_pe_w_dir = _ptr(pe_w_xyz), _ptr(pe_w_dir)
+    a.d_status = _ptr(_status_word(dev))
     _lib.check(_lib.lib().nfl_render_pass(field.h_plan, _ptr(field.d_plan), _ptr(field.packed), C.byref(a), _stream()),
                "nfl_render_pass")
     return out
@@ -521,10 +554,14 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                                    "(the fast 'f16' mode is inference-only)")
             outs = _RenderRaysFn.apply(cfg, rays_in if rays_grad else rays, a_emb, t_emb, *params)
             keys = [k for k in _result_keys(cfg)]
+            if kwargs.get("check_finite"):
+                check_status(dev)
             return dict(zip(keys, outs))
         a_c = None if a_emb is None else _f32c(a_emb, "a_embedded")
         t_c = None if t_emb is None else _f32c(t_emb, "t_embedded")
         result, _ = _forward(cfg, rays, a_c, t_c, train=False)
+        if kwargs.get("check_finite"):       # build-defined kwarg: synchronises; see check_status()
+            check_status(dev)
     return result
 
 

@@ -23,7 +23,7 @@ from . import parallel
 from .nerf import NeRF, PosEmbedding
 from .rendering import render_rays
 
-__all__ = ["NerfWLoss", "psnr", "Adam", "RayTrainer"]
+__all__ = ["NerfWLoss", "psnr", "Adam", "RayTrainer", "GraphedTrainStep"]
 
 
 class NerfWLoss(nn.Module):
@@ -116,8 +116,38 @@ class Adam(torch.optim.Optimizer):
     torch Optimizer otherwise: param_groups (LR schedulers work), state[p] = {step, exp_avg, exp_avg_sq} with
     torch's names, so state_dict()s are interchangeable with torch.optim.Adam's."""
 
-    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, capturable=False):
+        """capturable=True: learning rate, betas, eps and the step count are kept in device memory and read by the
+        kernel (C ABI `nfl_adam_step_dev`), so `step()` can be captured in a HIP graph and replayed while a scheduler
+        changes the rate (GraphedTrainStep); `sync_hyper()` uploads the current param_groups' values."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.capturable = bool(capturable)
+        self._dev = {}            # (group index, device) -> dict(hyper=float[4] tensor, step=int32 tensor, host=tuple)
+
+    def _dev_state(self, gi, group, dev):
+        k = (gi, str(dev))
+        if k not in self._dev:
+            steps = [int(self.state[p]["step"]) for p in group["params"] if self.state.get(p)]
+            self._dev[k] = dict(hyper=torch.zeros(4, dtype=torch.float32, device=dev),
+                                step=torch.full((1,), max(steps) if steps else 0, dtype=torch.int32, device=dev), host=None)
+        return self._dev[k]
+
+    def sync_hyper(self):
+        """Upload lr / betas / eps of every param group to the device copies the captured launches read (host -> device
+        copies: call it outside graph capture; GraphedTrainStep.replay() does)."""
+        for (gi, _dev), st in self._dev.items():
+            g = self.param_groups[gi]
+            host = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+            if st["host"] != host:
+                st["hyper"].copy_(torch.tensor(host, dtype=torch.float32))
+                st["host"] = host
+
+    def note_replay(self):
+        """A captured step() was replayed: advance the host-side step counts (state_dict compatibility)."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                if self.state.get(p):
+                    self.state[p]["step"] = int(self.state[p]["step"]) + 1
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -129,7 +159,8 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        for group in self.param_groups:
+        capturing = self.capturable and torch.cuda.is_current_stream_capturing()
+        for gi, group in enumerate(self.param_groups):
             todo = {}                            # (device, step) -> list of (p, grad, m, v)
             for p in group["params"]:
                 if p.grad is None:
@@ -141,26 +172,108 @@ class Adam(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["step"] = int(st["step"]) + 1
+                if not capturing:                # a captured launch runs at replay time: note_replay() counts it
+                    st["step"] = int(st["step"]) + 1
                 if not p.is_contiguous():
                     raise RuntimeError("nerf_fl_amd.train.Adam: parameters must be contiguous")
-                todo.setdefault((p.device, st["step"]), []).append((p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"]))
+                # capturable: one device-side counter per (group, device), so all of a group's tensors step together
+                todo.setdefault((p.device, 0 if self.capturable else st["step"]), []).append(
+                    (p, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"]))
             b1, b2 = group["betas"]
             for (dev, step), items in todo.items():
                 with torch.cuda.device(dev):
                     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                    if self.capturable:
+                        ds = self._dev_state(gi, group, dev)
+                        if not capturing:
+                            self.sync_hyper()
+                        elif ds["host"] is None:
+                            raise RuntimeError("nerf_fl_amd.train.Adam: run one eager step() (or sync_hyper()) before capture")
                     for i0 in range(0, len(items), _lib.NFL_ADAM_MAX_TENSORS):
                         chunk = items[i0:i0 + _lib.NFL_ADAM_MAX_TENSORS]
                         t = _lib.AdamTensors()
                         for k, (p, g, m, v) in enumerate(chunk):
                             t.param[k], t.grad[k], t.exp_avg[k], t.exp_avg_sq[k] = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
                             t.numel[k] = p.numel()
-                        _lib.check(L.nfl_adam_step(C.byref(t), len(chunk), float(group["lr"]), float(b1), float(b2),
-                                                   float(group["eps"]), step, stream), "nfl_adam_step")
+                        if self.capturable:
+                            last = i0 + _lib.NFL_ADAM_MAX_TENSORS >= len(items)
+                            _lib.check(L.nfl_adam_step_dev(C.byref(t), len(chunk), C.c_void_p(ds["hyper"].data_ptr()),
+                                                           C.c_void_p(ds["step"].data_ptr()), int(last), stream),
+                                       "nfl_adam_step_dev")
+                        else:
+                            _lib.check(L.nfl_adam_step(C.byref(t), len(chunk), float(group["lr"]), float(b1), float(b2),
+                                                       float(group["eps"]), step, stream), "nfl_adam_step")
                         # the kernel wrote the parameters behind autograd's back: bump their version counters, which
                         # is what tells render_rays to re-pack the weight streams (and autograd to refuse stale graphs)
                         torch.autograd.graph.increment_version([p for p, _, _, _ in chunk])
         return loss
+
+
+class GraphedTrainStep:
+    """One fixed-shape optimisation step -- weight re-pack, render_rays forward, NerfWLoss, the HIP backward, Adam --
+    captured ONCE into a HIP graph and replayed: a step becomes one graph launch (~35 kernel launches, ~25 allocations
+    and their Python disappear from the host's critical path; what matters at the README batch of 1024 rays, where the
+    kernels take ~1.3 ms).  Random draws come from torch's graph-safe Philox generator, so every replay draws afresh.
+
+    `opt` must be `Adam(..., capturable=True)`.  Batches are loaded into the static buffers with `load()`.
+    Construction runs `warmup` REAL steps eagerly (kernel attributes, optimizer state) before capturing.
+    With `all_reduce=True` (ranks > 1) the step is two graphs with the flat gradient all-reduce between them."""
+
+    def __init__(self, models, embeddings, params, opt, loss_fn, rays, ts, target, N_samples, N_importance,
+                 use_disp=False, perturb=1.0, noise_std=1.0, white_back=True, all_reduce=False, warmup=2):
+        if not getattr(opt, "capturable", False):
+            raise ValueError("GraphedTrainStep needs nerf_fl_amd.train.Adam(capturable=True)")
+        self.params, self.opt, self.all_reduce = list(params), opt, bool(all_reduce)
+        self.rays, self.ts, self.target = rays.detach().clone(), ts.detach().clone(), target.detach().clone()
+        dev = self.rays.device
+
+        def fwd_bwd():
+            opt.zero_grad(set_to_none=True)
+            res = render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, perturb, noise_std,
+                              N_importance, 32768, white_back, False)
+            total = sum(loss_fn(res, self.target).values())
+            total.backward()
+            key = "rgb_fine" if "rgb_fine" in res else "rgb_coarse"
+            return total.detach(), psnr(res[key].detach(), self.target)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                fwd_bwd()
+                if self.all_reduce:
+                    parallel.all_reduce_gradients(self.params)
+                opt.step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        self.graph_opt = None
+        with torch.cuda.graph(self.graph):
+            self.out = fwd_bwd()
+            if not self.all_reduce:
+                opt.step()
+        if self.all_reduce:
+            self.graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                opt.step()
+
+    def load(self, rays, ts, target):
+        self.rays.copy_(rays)
+        self.ts.copy_(ts)
+        self.target.copy_(target)
+
+    def replay(self):
+        """Run the captured step on the loaded batch; returns (loss, psnr) as device scalars (valid until the next replay)."""
+        self.opt.sync_hyper()
+        self.graph.replay()
+        if self.graph_opt is not None:
+            parallel.all_reduce_gradients(self.params)
+            self.graph_opt.replay()
+        self.opt.note_replay()
+        # the parameters changed behind autograd's back: move their version counters so that any eager render_rays
+        # (validation) re-packs its weight streams
+        torch.autograd.graph.increment_version(self.params)
+        return self.out
 
 
 class RayTrainer:

@@ -419,3 +419,19 @@ def make_rays(n_rays: int, seed: int, near: float = 2.0, far: float = 6.0) -> Te
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     nf = np.stack([np.full(n_rays, near), np.full(n_rays, far)], axis=1)
     return torch.from_numpy(np.concatenate([o, d, nf], axis=1).astype(np.float32))
+
+
+def make_rays_photo(n_rays: int, seed: int) -> Tensor:
+    """Phototourism-like rays (reference datasets/phototourism.py:130-140, 173-183): cameras scattered in front of the
+    scene, unit directions, and near/far DIFFERENT ON EVERY RAY (per-image depth percentiles, rescaled so that the
+    largest far bound is 5)."""
+    rng = np.random.default_rng(seed)
+    o = np.array([0.0, 0.0, 2.5]) + rng.uniform(-1.0, 1.0, size=(n_rays, 3)) * np.array([1.5, 0.5, 0.7])
+    tgt = rng.uniform(-1, 1, size=(n_rays, 3)) * np.array([1.2, 0.8, 0.5])
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    near = rng.uniform(0.05, 1.5, size=n_rays)
+    far = near + rng.uniform(1.0, 3.5, size=n_rays)
+    far *= 5.0 / far.max()
+    near = np.minimum(near, 0.6 * far)
+    return torch.from_numpy(np.concatenate([o, d, near[:, None], far[:, None]], axis=1).astype(np.float32))

@@ -37,10 +37,23 @@ def ref_field(spec: orc.FieldSpec, seed: int, regime: str, refine_pose: bool = F
              encode_appearance=spec.encode_appearance, in_channels_a=spec.n_a,
              encode_transient=spec.encode_transient, in_channels_t=spec.n_tau,
              beta_min=spec.beta_min, refine_pose=refine_pose)
-    P = orc.make_field_params(spec, seed, regime)
+    P = trained_params(spec) if regime == "trained" else orc.make_field_params(spec, seed, regime)
     missing = m.load_state_dict(P, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return m
+
+
+TRAINED = os.path.join(HERE, "w_trained.npz")
+
+
+def trained_params(spec: orc.FieldSpec):
+    """Weights of the reference after `train_reference()` (tests/golden/w_trained.npz): the coarse field for every
+    base-shaped field, the NeRF-W fine field otherwise."""
+    z = np.load(TRAINED, allow_pickle=False)
+    tag = "fine" if (spec.encode_appearance or spec.encode_transient) else "coarse"
+    if tag == "fine":
+        assert spec.encode_appearance and spec.encode_transient
+    return {k[len(tag) + 1:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(tag + ".")}
 
 
 def save(name, cfg, **arrays):
@@ -136,11 +149,109 @@ def g3_sample_pdf():
     save("g3_sample_pdf", {"n_importance": I}, bins=bins_t, weights=w_t, u=u_t, det=det, rnd=rnd)
 
 
+def g3b_sample_pdf_from_coarse():
+    """sample_pdf exactly as render_rays calls it (rendering.py:266-272): bins = mid-points of the coarse depths,
+    weights = the interior coarse weights, then concat + sort.  Same edge cases as g3 (empty rays, runs of zero
+    weight, a spike, u = 0 / 1 / 1 - 2^-24) plus per-ray depth ranges; this is what the C ABI's nfl_sample_pdf
+    takes, so the HIP kernel can be tested on it directly."""
+    rng = np.random.default_rng(404)
+    R, S, I = 48, 64, 64
+    near = rng.uniform(0.05, 2.0, size=(R, 1)).astype(np.float32)
+    far = (near + rng.uniform(1.0, 4.0, size=(R, 1))).astype(np.float32)
+    steps = np.linspace(0, 1, S, dtype=np.float32)[None]
+    z = near * (1 - steps) + far * steps
+    mid = 0.5 * (z[:, :-1] + z[:, 1:])
+    lower, upper = np.concatenate([z[:, :1], mid], 1), np.concatenate([mid, z[:, -1:]], 1)
+    z[24:] = (lower + (upper - lower) * rng.uniform(0, 1, size=(R, S)).astype(np.float32))[24:]   # jittered rows
+    w = rng.uniform(0, 1, size=(R, S)).astype(np.float32) ** 4
+    w[:8, 10:40] = 0.0              # runs of empty bins
+    w[8:12, :] = 0.0                # completely empty rays
+    w[12:16, :] = 0.0
+    w[12:16, 31] = 1.0              # one spike
+    w[16:20, 1:-1] = 0.0            # weight only in the two columns sample_pdf drops
+    z_t, w_t = torch.from_numpy(z), torch.from_numpy(w)
+    mids = 0.5 * (z_t[:, :-1] + z_t[:, 1:])
+    det = sample_pdf(mids, w_t[:, 1:-1], I, det=True)
+    u = rng.uniform(0, 1, size=(R, I)).astype(np.float32)
+    u[:, 0] = 0.0
+    u[:, 1] = 1.0
+    u[:, 2] = np.float32(1.0) - np.float32(2 ** -24)
+    u_t = torch.from_numpy(u)
+    orig = torch.rand
+    torch.rand = lambda *a, **k: u_t.clone()
+    try:
+        rnd = sample_pdf(mids, w_t[:, 1:-1], I, det=False)
+    finally:
+        torch.rand = orig
+    save("g3b_sample_pdf_coarse", {"n_samples": S, "n_importance": I}, z_coarse=z_t, weights_coarse=w_t, u=u_t,
+         det=det, rnd=rnd, z_fine_det=torch.sort(torch.cat([z_t, det], -1), -1)[0],
+         z_fine_rnd=torch.sort(torch.cat([z_t, rnd], -1), -1)[0])
+
+
+def _scene_colors(rays, ts, n_vocab, rng):
+    """Analytic target for train_reference(): a shaded unit sphere in front of a white background, a per-image tint
+    (appearance) and, on every third image, a grey occluder over part of the view (transient)."""
+    o, d = rays[:, :3].numpy().astype(np.float64), rays[:, 3:6].numpy().astype(np.float64)
+    b = (o * d).sum(1)
+    disc = b * b - ((o * o).sum(1) - 1.0)
+    hit = disc > 0
+    t = -b - np.sqrt(np.where(hit, disc, 0.0))
+    n = o + d * t[:, None]
+    stripes = 0.5 + 0.5 * np.sign(np.sin(9.0 * n[:, 0]) * np.sin(9.0 * n[:, 1]))
+    col = np.clip(0.5 + 0.5 * n, 0, 1) * (0.55 + 0.45 * stripes[:, None])
+    tint = 0.75 + 0.25 * np.random.default_rng(5).uniform(-1, 1, size=(n_vocab, 3))
+    col = np.where(hit[:, None], col * tint[ts.numpy()], 1.0)
+    occ = (ts.numpy() % 3 == 0) & (d[:, 0] > 0.05)
+    col = np.where(occ[:, None], 0.35, col)
+    return torch.from_numpy(np.clip(col, 0, 1).astype(np.float32))
+
+
+def train_reference(steps=400, R=512, n_vocab=20, lr=1e-3):
+    """'Trained-like' weights (random-init weights have a narrower dynamic range than trained ones): fit
+    the REAL reference (coarse base field + NeRF-W fine field + latent tables, NerfWLoss, Adam) to an analytic scene
+    for a few hundred steps on the CPU and store the resulting state_dicts.  The low 8 mantissa bits of every weight
+    are cleared before storing (keeps the file compressible; the fixtures are generated FROM the stored values, so
+    nothing is lost)."""
+    torch.manual_seed(77)
+    spec_c = orc.FieldSpec("coarse")
+    spec_f = orc.FieldSpec("fine", encode_appearance=True, encode_transient=True, beta_min=0.1)
+    mc, mf = ref_field(spec_c, 71, "default"), ref_field(spec_f, 72, "default")
+    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4), "a": torch.nn.Embedding(n_vocab, 48),
+           "t": torch.nn.Embedding(n_vocab, 16)}
+    params = list(mc.parameters()) + list(mf.parameters()) + list(emb["a"].parameters()) + list(emb["t"].parameters())
+    opt = torch.optim.Adam(params, lr=lr, eps=1e-8)
+    loss_fn = loss_dict["nerfw"]()
+    rng = np.random.default_rng(78)
+    for it in range(steps):
+        rays = orc.make_rays(R, 1000 + it)
+        ts = torch.from_numpy(rng.integers(0, n_vocab, size=R).astype(np.int64))
+        target = _scene_colors(rays, ts, n_vocab, rng)
+        opt.zero_grad()
+        res = render_rays({"coarse": mc, "fine": mf}, emb, rays, ts, 64, False, 1.0, 1.0, 64, 32768, True, False)
+        losses = loss_fn(res, target)
+        sum(losses.values()).backward()
+        opt.step()
+        if it % 20 == 0 or it == steps - 1:
+            mse = ((res["rgb_fine"].detach() - target) ** 2).mean().item()
+            print(f"train_reference step {it}: " + " ".join(f"{k}={float(v):.4f}" for k, v in losses.items())
+                  + f" psnr_fine={-10 * np.log10(mse):.2f}", flush=True)
+    out = {}
+    for tag, m in (("coarse", mc), ("fine", mf)):
+        for k, v in m.state_dict().items():
+            bits = v.detach().numpy().view(np.uint32) & np.uint32(0xFFFFFF00)
+            out[f"{tag}.{k}"] = bits.view(np.float32)
+    for k in ("a", "t"):
+        out[f"table_{k}"] = emb[k].weight.detach().numpy()
+    np.savez_compressed(TRAINED, **out)
+    print("wrote", TRAINED)
+
+
 def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, use_disp=False,
                 perturb=0.0, noise_std=0.0, test_time=False, n_vocab=20, kwargs_mode="ts",
                 output_transient=None, grads=False, rays_grad=False, near=2.0, far=6.0, seed=11,
-                n_emb_xyz=10, barf_epoch=None):
-    """fine: None | 'base' | 'a' | 'at'."""
+                n_emb_xyz=10, barf_epoch=None, rays_kind="blender", view_dir=False, beta_min=0.1):
+    """fine: None | 'base' | 'a' | 'at'.  rays_kind 'photo': per-ray near/far (phototourism); view_dir: pass a
+    `view_dir` kwarg that differs from rays_d (rendering.py:236-238)."""
     spec_c = orc.FieldSpec("coarse", n_emb_xyz=n_emb_xyz)
     barf = barf_epoch is not None
     mc = ref_field(spec_c, seed, regime, refine_pose=barf)
@@ -152,13 +263,13 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
     cfg = dict(R=R, S=S, I=I, fine=fine, regime=regime, white_back=white_back, use_disp=use_disp,
                perturb=perturb, noise_std=noise_std, test_time=test_time, n_vocab=n_vocab,
                kwargs_mode=kwargs_mode, output_transient=output_transient, seed=seed,
-               n_emb_xyz=n_emb_xyz, beta_min=0.1, barf_epoch=barf_epoch)
+               n_emb_xyz=n_emb_xyz, beta_min=beta_min, barf_epoch=barf_epoch, rays_kind=rays_kind)
     spec_f = None
     if fine is not None:
         spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, encode_appearance=fine in ("a", "at"),
-                               encode_transient=fine == "at", beta_min=0.1)
+                               encode_transient=fine == "at", beta_min=beta_min)
         models["fine"] = ref_field(spec_f, seed + 1, regime, refine_pose=barf)
-    rays = orc.make_rays(R, seed + 2, near, far)
+    rays = orc.make_rays_photo(R, seed + 2) if rays_kind == "photo" else orc.make_rays(R, seed + 2, near, far)
     rng = np.random.default_rng(seed + 3)
     ts = torch.from_numpy(rng.integers(0, n_vocab, size=R).astype(np.int64))
     arrays = {"rays": rays, "ts": ts}
@@ -167,13 +278,15 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
         kwargs["current_epoch"] = barf_epoch
     a_emb = t_emb = None
     if spec_f is not None and spec_f.encode_appearance:
-        table_a = orc.make_embedding_table(n_vocab, 48, seed + 4)
+        table_a = (torch.from_numpy(np.load(TRAINED)["table_a"]) if regime == "trained"
+                   else orc.make_embedding_table(n_vocab, 48, seed + 4))
         emb = torch.nn.Embedding(n_vocab, 48)
         emb.weight.data.copy_(table_a)
         embeddings["a"] = emb
         a_emb = table_a[ts].clone()
     if spec_f is not None and spec_f.encode_transient:
-        table_t = orc.make_embedding_table(n_vocab, 16, seed + 5)
+        table_t = (torch.from_numpy(np.load(TRAINED)["table_t"]) if regime == "trained"
+                   else orc.make_embedding_table(n_vocab, 16, seed + 5))
         emb = torch.nn.Embedding(n_vocab, 16)
         emb.weight.data.copy_(table_t)
         embeddings["t"] = emb
@@ -187,6 +300,10 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
             kwargs["t_embedded"] = t_emb
     if output_transient is not None:
         kwargs["output_transient"] = output_transient
+    if view_dir:
+        vd = np.random.default_rng(seed + 7).standard_normal((R, 3))
+        vd /= np.linalg.norm(vd, axis=1, keepdims=True)
+        arrays["view_dir"] = kwargs["view_dir"] = torch.from_numpy(vd.astype(np.float32))
     if rays_grad:
         rays.requires_grad_(True)
     for p in list(mc.parameters()) + (list(models["fine"].parameters()) if fine else []):
@@ -239,49 +356,87 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
 
 
 def main():
-    g1_posenc()
-    g2_field()
-    g3_sample_pdf()
+    want = sys.argv[1:]
+    sel = lambda name: not want or any(name.startswith(w) for w in want)
+    if "train" in want:
+        train_reference()
+        return
+    if sel("g1_"):
+        g1_posenc()
+    if sel("g2_"):
+        g2_field()
+    if sel("g3_"):
+        g3_sample_pdf()
+    if sel("g3b_"):
+        g3b_sample_pdf_from_coarse()
+    for name, kw in RENDER_CASES:
+        if sel(name):
+            render_case(name, **kw)
+
+
+RENDER_CASES = [
     # G4: cfg-1 shape, coarse only
-    render_case("g4_cfg1_coarse", R=64, S=32, I=0, white_back=True)
-    render_case("g4_cfg1_coarse_default", R=64, S=32, I=0, white_back=True, regime="default")
+    ("g4_cfg1_coarse", dict(R=64, S=32, I=0, white_back=True)),
+    ("g4_cfg1_coarse_default", dict(R=64, S=32, I=0, white_back=True, regime="default")),
     # G5: cfg-2 shape, base coarse + base fine
-    render_case("g5_cfg2_base", R=64, S=64, I=64, fine="base", white_back=True)
-    render_case("g5_cfg2_base_default", R=64, S=64, I=64, fine="base", white_back=True, regime="default")
+    ("g5_cfg2_base", dict(R=64, S=64, I=64, fine="base", white_back=True)),
+    ("g5_cfg2_base_default", dict(R=64, S=64, I=64, fine="base", white_back=True, regime="default")),
     # G6: cfg-3 shape, NeRF-W a+t, train keys
-    render_case("g6_cfg3_nerfw", R=64, S=64, I=64, fine="at", white_back=True)
-    render_case("g6_cfg3_nerfa", R=64, S=64, I=64, fine="a", white_back=True)
+    ("g6_cfg3_nerfw", dict(R=64, S=64, I=64, fine="at", white_back=True)),
+    ("g6_cfg3_nerfa", dict(R=64, S=64, I=64, fine="a", white_back=True)),
     # G7: test_time keys; output_transient=False + a_embedded kwarg
-    render_case("g7_test_nerfw", R=64, S=64, I=64, fine="at", white_back=True, test_time=True)
-    render_case("g7_test_nerfw_noT", R=64, S=64, I=64, fine="at", white_back=False, test_time=True,
-                kwargs_mode="embedded", output_transient=False)
-    # G8: disparity sampling; G9: black background, per-ray near/far like phototourism
-    render_case("g8_use_disp", R=64, S=64, I=64, fine="base", white_back=True, use_disp=True)
-    render_case("g9_black_back", R=64, S=64, I=64, fine="at", white_back=False, near=0.5, far=5.0)
+    ("g7_test_nerfw", dict(R=64, S=64, I=64, fine="at", white_back=True, test_time=True)),
+    ("g7_test_nerfw_noT", dict(R=64, S=64, I=64, fine="at", white_back=False, test_time=True,
+                               kwargs_mode="embedded", output_transient=False)),
+    # G8: disparity sampling; G9: black background, near/far 0.5/5 (the same on every ray; per-ray bounds: G15)
+    ("g8_use_disp", dict(R=64, S=64, I=64, fine="base", white_back=True, use_disp=True)),
+    ("g9_black_back", dict(R=64, S=64, I=64, fine="at", white_back=False, near=0.5, far=5.0)),
     # G10: cfg-5 shape 128+128, sigma-only coarse, N_emb_xyz=15 like the phototourism notebook
-    render_case("g10_cfg5", R=32, S=128, I=128, fine="at", white_back=False, test_time=True, near=0.3, far=5.0)
-    render_case("g10_cfg5_xyz15", R=32, S=128, I=128, fine="a", white_back=False, test_time=True,
-                n_emb_xyz=15, near=0.3, far=5.0)
+    ("g10_cfg5", dict(R=32, S=128, I=128, fine="at", white_back=False, test_time=True, near=0.3, far=5.0)),
+    ("g10_cfg5_xyz15", dict(R=32, S=128, I=128, fine="a", white_back=False, test_time=True,
+                            n_emb_xyz=15, near=0.3, far=5.0)),
     # odd sizes: ragged sample counts (reference default N_importance=128 with 64 coarse)
-    render_case("g13_ragged", R=37, S=24, I=40, fine="base", white_back=True)
-    render_case("g13_64_128", R=33, S=64, I=128, fine="at", white_back=False)
+    ("g13_ragged", dict(R=37, S=24, I=40, fine="base", white_back=True)),
+    ("g13_64_128", dict(R=33, S=64, I=128, fine="at", white_back=False)),
     # G11: gradients
-    render_case("g11_grad_cfg1", R=64, S=32, I=0, white_back=True, grads=True)
-    render_case("g11_grad_cfg2", R=64, S=64, I=64, fine="base", white_back=True, grads=True)
-    render_case("g11_grad_cfg3", R=64, S=64, I=64, fine="at", white_back=True, grads=True,
-                kwargs_mode="embedded")
-    render_case("g11_grad_cfg3_ts", R=64, S=64, I=64, fine="at", white_back=False, grads=True)
-    render_case("g11_grad_rays", R=32, S=32, I=32, fine="base", white_back=True, grads=True, rays_grad=True)
+    ("g11_grad_cfg1", dict(R=64, S=32, I=0, white_back=True, grads=True)),
+    ("g11_grad_cfg2", dict(R=64, S=64, I=64, fine="base", white_back=True, grads=True)),
+    ("g11_grad_cfg3", dict(R=64, S=64, I=64, fine="at", white_back=True, grads=True, kwargs_mode="embedded")),
+    ("g11_grad_cfg3_ts", dict(R=64, S=64, I=64, fine="at", white_back=False, grads=True)),
+    ("g11_grad_rays", dict(R=32, S=32, I=32, fine="base", white_back=True, grads=True, rays_grad=True)),
     # G12: stochastic runs with captured draws
-    render_case("g12_stoch_base", R=64, S=64, I=64, fine="base", white_back=True, perturb=1.0, noise_std=1.0)
-    render_case("g12_stoch_nerfw", R=64, S=64, I=64, fine="at", white_back=True, perturb=1.0, noise_std=1.0)
-    render_case("g12_stoch_grad", R=64, S=64, I=64, fine="base", white_back=True, perturb=1.0, noise_std=1.0,
-                grads=True)
+    ("g12_stoch_base", dict(R=64, S=64, I=64, fine="base", white_back=True, perturb=1.0, noise_std=1.0)),
+    ("g12_stoch_nerfw", dict(R=64, S=64, I=64, fine="at", white_back=True, perturb=1.0, noise_std=1.0)),
+    ("g12_stoch_grad", dict(R=64, S=64, I=64, fine="base", white_back=True, perturb=1.0, noise_std=1.0, grads=True)),
     # G14: learnable-pose mode: BARF-weighted encodings (epochs inside and after the ramp) + gradient w.r.t. rays
-    render_case("g14_barf_e6", R=32, S=32, I=32, fine="base", white_back=True, grads=True, rays_grad=True, barf_epoch=6)
-    render_case("g14_barf_e9", R=32, S=64, I=64, fine="at", white_back=False, grads=True, rays_grad=True, barf_epoch=9,
-                kwargs_mode="embedded")
-    render_case("g14_barf_e2_fwd", R=32, S=32, I=32, fine="base", white_back=True, barf_epoch=2)
+    ("g14_barf_e6", dict(R=32, S=32, I=32, fine="base", white_back=True, grads=True, rays_grad=True, barf_epoch=6)),
+    ("g14_barf_e9", dict(R=32, S=64, I=64, fine="at", white_back=False, grads=True, rays_grad=True, barf_epoch=9,
+                         kwargs_mode="embedded")),
+    ("g14_barf_e2_fwd", dict(R=32, S=32, I=32, fine="base", white_back=True, barf_epoch=2)),
+    # G15: configs[3] on one GPU -- Phototourism shape (README.md:113-120): batch 1024, 64+64, NeRF-W a+t, black
+    # background, N_vocab 1500 through the embedding tables, beta_min 0.03, near/far different on every ray;
+    # deterministic and stochastic, forward + gradients (incl. the dense table gradients)
+    ("g15_photo_grad", dict(R=1024, S=64, I=64, fine="at", white_back=False, n_vocab=1500, beta_min=0.03,
+                            rays_kind="photo", grads=True, noise_std=1.0, seed=15)),
+    ("g15_photo_stoch", dict(R=256, S=64, I=64, fine="at", white_back=False, n_vocab=1500, beta_min=0.03,
+                             rays_kind="photo", perturb=1.0, noise_std=1.0, grads=True, seed=16)),
+    ("g15_photo_test", dict(R=128, S=128, I=128, fine="at", white_back=False, n_vocab=1500, beta_min=0.03,
+                            rays_kind="photo", test_time=True, seed=17, use_disp=True)),
+    # G16: the view_dir kwarg (rendering.py:236-238): direction encoding of a vector other than rays_d
+    ("g16_view_dir", dict(R=64, S=64, I=64, fine="a", white_back=True, view_dir=True, grads=True, seed=18)),
+    ("g16_view_dir_test", dict(R=48, S=32, I=32, fine="at", white_back=False, view_dir=True, test_time=True, seed=19,
+                               rays_kind="photo")),
+    # G17: weights after a few hundred Adam steps of the reference (train_reference): cfg 2 and cfg 3, forward
+    # (deterministic, stochastic, test_time) and gradients
+    ("g17_trained_cfg2", dict(R=64, S=64, I=64, fine="base", white_back=True, regime="trained", grads=True, seed=21)),
+    ("g17_trained_cfg3", dict(R=64, S=64, I=64, fine="at", white_back=True, regime="trained", grads=True, seed=22)),
+    ("g17_trained_cfg3_stoch", dict(R=64, S=64, I=64, fine="at", white_back=True, regime="trained", perturb=1.0,
+                                    noise_std=1.0, seed=23)),
+    ("g17_trained_cfg2_stoch", dict(R=64, S=64, I=64, fine="base", white_back=True, regime="trained", perturb=1.0,
+                                    noise_std=1.0, grads=True, seed=24)),
+    ("g17_trained_test", dict(R=32, S=128, I=128, fine="at", white_back=True, regime="trained", test_time=True,
+                              seed=25)),
+]
 
 
 if __name__ == "__main__":

@@ -43,6 +43,8 @@ def hip_render(specs, rays, kw, precision="f16x3", field_raw=False):
         extra["a_embedded"] = kw["a_emb"].to(DEV)
     if kw.get("t_emb") is not None:
         extra["t_embedded"] = kw["t_emb"].to(DEV)
+    if kw.get("view_dir") is not None:
+        extra["view_dir"] = kw["view_dir"].to(DEV)
     if not kw.get("output_transient", True):
         extra["output_transient"] = False
     if field_raw:

@@ -1,0 +1,40 @@
+"""`python bench.py --gpus N` must start its own ranks, report the size of the process group that actually ran, and
+fail loudly when a rank dies or when the group does not match --gpus (VERDICT r1 missing #1).  Exercised here without a
+GPU through bench.py's --dry mode: same launcher, gloo on 127.0.0.1, the same flat gradient all-reduce."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=180):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_self_launch_two_ranks_dry():
+    p = _run(["--gpus", "2", "--dry", "--steps", "2"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, printed by rank 0"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["allreduce_ok"] is True and out["dry"] is True
+
+
+def test_a_failing_rank_fails_the_launch():
+    p = _run(["--gpus", "2", "--dry", "--steps", "1"], {"NFL_BENCH_FAIL_RANK": "1"})
+    assert p.returncode != 0
+    assert "rank 1 exited" in p.stderr
+
+
+def test_refuses_a_process_group_of_another_size():
+    """Under an external launcher (WORLD_SIZE set) --gpus must equal the group size: no silent n_gpus = 1 for --gpus 8."""
+    p = _run(["--gpus", "8", "--dry"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                        "MASTER_PORT": "29999"})
+    assert p.returncode != 0
+    assert "refusing" in p.stderr
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -133,3 +133,34 @@ def test_auxiliary_entry_points_validate_arguments(L):
     assert L.nfl_posenc(None, 4, 10, None, None, None) == -1
     assert L.nfl_composite_backward(None, None) == -1 and L.nfl_mlp_dgrad(None, None, None, None, None) == -1
     assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, None, None) == -1
+
+
+def test_adam_step_dev_validates_arguments(L):
+    t = _lib.AdamTensors()
+    assert L.nfl_adam_step_dev(None, 1, C.c_void_p(16), C.c_void_p(16), 1, None) == -1
+    assert L.nfl_adam_step_dev(C.byref(t), 1, None, C.c_void_p(16), 1, None) == -1          # hyper-parameters missing
+    assert L.nfl_adam_step_dev(C.byref(t), 1, C.c_void_p(16), None, 1, None) == -1          # step counter missing
+    assert L.nfl_adam_step_dev(C.byref(t), 0, C.c_void_p(16), C.c_void_p(16), 1, None) == 0
+
+
+def test_synth_generators_equal_the_oracles():
+    """bench.py's GPU side draws its weights and rays from nerf_fl_amd.synth, its cpu_baseline leg and the tests from
+    the oracle's own copies: the two must stay the same numbers."""
+    import torch
+    from nerf_fl_amd import synth
+    from oracle import nerfw_oracle as orc
+    for typ, kw in (("coarse", {}), ("fine", dict(encode_appearance=True, encode_transient=True)),
+                    ("fine", dict(encode_appearance=True)), ("fine", dict(n_emb_xyz=15))):
+        for regime in ("default", "sharp"):
+            a = synth.make_field_params(7, regime, typ=typ, **kw)
+            b = orc.make_field_params(orc.FieldSpec(typ, **kw), 7, regime)
+            assert list(a) == list(b) and all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.equal(synth.make_rays(100, 3, 0.5, 5.0), orc.make_rays(100, 3, 0.5, 5.0))
+    assert torch.equal(synth.make_rays_photo(100, 3), orc.make_rays_photo(100, 3))
+
+
+def test_product_package_never_imports_the_oracle():
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "nerf_fl_amd", "*.py")):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path

@@ -1,9 +1,19 @@
-"""GPU gradient parity: the hand-written HIP backward (composite -> dgrad -> wgrad)
-against the gradients autograd produced through the REAL reference (golden vectors
-g11_*/g12_stoch_grad), for loss = sum(NerfWLoss).  The forward is fp32-class
-(f16x3); the backward multiplies in bf16 (dgrad split 3x, wgrad single product over
->= 2048 samples), so the tolerance is relative: |g - g_ref| <= GTOL * max|g_ref|
-per tensor."""
+"""GPU gradient parity: the hand-written HIP backward (composite -> dgrad -> wgrad) against the gradients autograd
+produced through the REAL reference (golden vectors g11_* / g12_stoch_grad / g14_* / g15_* / g16_* / g17_*), for
+loss = sum(NerfWLoss).
+
+Arithmetic under test: the forward is fp32-class (f16x3); the MLP part of the backward multiplies in fp16 (one
+product, fp32 accumulation) on fp16-stashed activations and loss-scaled fp16 gradients, so its
+error is a few 2^-11 relative per product, averaged over the samples of the batch.  Four measures per tensor, each with
+its own threshold (about 2x the largest value measured over all cases, tests/report_grads.py prints them):
+
+  max   max|g - ref| / max|ref|              every element, on the scale of the tensor
+  elem  max|g - ref| / |ref|                 over elements with |ref| >= 1e-3 max|ref|: no small-but-wrong entries
+  norm  | ||g|| - ||ref|| | / ||ref||        whole tensor
+  proj  |<g, r> - <ref, r>| / ||ref||        a fixed random direction r (N(0,1), seed 99): the WHOLE of a big tensor,
+                                             of which the fixture otherwise stores only four rows
+"""
+import numpy as np
 import pytest
 import torch
 
@@ -11,15 +21,33 @@ import golden_util as gu
 from oracle import nerfw_oracle as orc
 
 pytestmark = pytest.mark.gpu
-GTOL = 1e-2
 CASES = ["g11_grad_cfg1", "g11_grad_cfg2", "g11_grad_cfg3", "g11_grad_cfg3_ts", "g12_stoch_grad",
-         "g11_grad_rays", "g14_barf_e6", "g14_barf_e9"]      # the last three also check d/d rays (learnable poses)
+         "g11_grad_rays", "g14_barf_e6", "g14_barf_e9",      # the last three also check d/d rays (learnable poses)
+         "g15_photo_grad", "g15_photo_stoch",                # configs[3]: N_vocab 1500 tables, per-ray near/far, R 1024
+         "g16_view_dir",                                     # view_dir kwarg
+         "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch"]   # weights after 400 reference Adam steps
+
+# thresholds: measure -> (default, {tensor-name substring: override})
+THRESH = {
+    "max": (4e-3, {}),
+    "elem": (2.5e-2, {}),
+    "norm": (2e-3, {}),
+    "proj": (3e-3, {}),
+}
+
+
+def _limit(measure, key):
+    default, over = THRESH[measure]
+    for sub, v in over.items():
+        if sub in key:
+            return v
+    return default
 
 
 def run_case(name):
     import gpu_util
     import nerf_fl_amd
-    from nerf_fl_amd import PosEmbedding, render_rays
+    from nerf_fl_amd import render_rays
     cfg, a = gu.load(name)
     (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
     nerf_fl_amd.set_precision("f16x3")
@@ -35,6 +63,8 @@ def run_case(name):
     for k in ("perturb_rand", "noise_coarse", "u", "noise_fine"):
         if kw.get(k) is not None:
             extra[k] = kw[k].to(dev)
+    if kw.get("view_dir") is not None:
+        extra["view_dir"] = kw["view_dir"].to(dev)
     ts = a["ts"].to(dev)
     if cfg["kwargs_mode"] == "embedded":
         for k, kk in (("a_emb", "a_embedded"), ("t_emb", "t_embedded")):
@@ -42,10 +72,11 @@ def run_case(name):
                 leaves[k] = kw[k].to(dev).requires_grad_(True)
                 extra[kk] = leaves[k]
     else:
-        for k, dim, off in (("a", 48, 4), ("t", 16, 5)):
+        for k, dim in (("a", 48), ("t", 16)):
             if kw.get(k + "_emb") is not None:
-                e = torch.nn.Embedding(cfg["n_vocab"], dim).to(dev)
-                e.weight.data.copy_(orc.make_embedding_table(cfg["n_vocab"], dim, cfg["seed"] + off))
+                table = gu.embedding_table(cfg, k)
+                e = torch.nn.Embedding(table.shape[0], dim).to(dev)
+                e.weight.data.copy_(table)
                 emb[k] = e
                 leaves["table_" + k] = e.weight
     rays = a["rays"].to(dev)
@@ -67,29 +98,49 @@ def run_case(name):
     return cfg, a, got, float(loss.detach())
 
 
+def _elem_rel(g, ref):
+    big = ref.abs() >= 1e-3 * ref.abs().max()
+    return ((g - ref).abs()[big] / ref.abs()[big]).max().item() if big.any() else 0.0
+
+
 def compare(cfg, a, got):
-    """yield (key, max abs err, max abs ref)"""
+    """yield (measure, key, value): the four measures of the module docstring for every tensor the fixture holds"""
     for key, exp in a.items():
         if key == "grad.rays":      # origin and direction columns; near/far carry no gradient here (they are data)
-            yield key, (got["rays"][:, :6] - exp[:, :6]).abs().max().item(), exp[:, :6].abs().max().item()
+            g, ref = got["rays"][:, :6], exp[:, :6]
+            yield "max", key, (g - ref).abs().max().item() / ref.abs().max().item()
+            yield "elem", key, _elem_rel(g, ref)
+            yield "norm", key, abs(g.norm().item() - ref.norm().item()) / ref.norm().item()
         elif key.startswith("grad."):
-            yield key, (got[key[5:]] - exp).abs().max().item(), exp.abs().max().item()
+            g = got[key[5:]]
+            if exp.abs().max().item() == 0.0:
+                assert g.abs().max().item() == 0.0, key
+                continue
+            yield "max", key, (g - exp).abs().max().item() / exp.abs().max().item()
+            yield "elem", key, _elem_rel(g, exp)
+            yield "norm", key, abs(g.norm().item() - exp.norm().item()) / exp.norm().item()
         elif key.startswith("gradrows."):
-            yield key, (got[key[9:]][:4] - exp).abs().max().item(), exp.abs().max().item()
+            g = got[key[9:]][:4]
+            yield "max", key, (g - exp).abs().max().item() / exp.abs().max().item()
+            yield "elem", key, _elem_rel(g, exp)
         elif key.startswith("gradnorm."):
-            yield key, abs(got[key[9:]].norm().item() - exp.item()), exp.item()
+            yield "norm", key, abs(got[key[9:]].norm().item() - exp.item()) / exp.item()
+        elif key.startswith("gradproj."):
+            g = got[key[9:]]
+            pr = torch.from_numpy(np.random.default_rng(99).standard_normal(g.numel()).astype(np.float32))
+            yield "proj", key, abs(float((g.flatten().double() * pr.double()).sum()) - exp.item()) / a["gradnorm." + key[9:]].item()
 
 
 @pytest.mark.parametrize("name", CASES)
 def test_gradients_vs_reference(name):
     cfg, a, got, loss = run_case(name)
     assert abs(loss - a["loss"].item()) <= 1e-4 * max(1.0, abs(a["loss"].item()))
-    bad, n = {}, 0
-    for key, err, ref in compare(cfg, a, got):
-        n += 1
-        if not err <= GTOL * ref + 1e-7:
-            bad[key] = (err, ref)
-    assert n > 10
+    bad, seen = {}, {m: 0 for m in THRESH}
+    for measure, key, val in compare(cfg, a, got):
+        seen[measure] += 1
+        if not val <= _limit(measure, key):
+            bad[(measure, key)] = (val, _limit(measure, key))
+    assert seen["max"] > 10 and seen["elem"] > 10 and seen["norm"] > 10
+    if any(k.startswith("gradproj.") for k in a):
+        assert seen["proj"] >= 5
     assert not bad, f"{name}: {bad}"
-
-

@@ -1,0 +1,160 @@
+"""Direct parity of the HIP `nfl_sample_pdf` (C ABI) with the reference's sample_pdf + concat + sort
+(models/rendering.py:7-46, 266-272) on the reference's edge cases: completely empty rays, runs of zero-weight
+bins, a single spike, weight only in the two dropped columns, u = 0 / 1 / 1 - 2^-24, per-ray depth ranges,
+jittered coarse depths.  Fixture: tests/golden/g3b_sample_pdf_coarse.npz, produced by the real reference.
+
+What "equal" means here.  Given the same normalising sum the kernel reproduces the reference's CPU arithmetic
+operation for operation (fp64-accumulated cumsum included, see nfl_sample.hip); the one quantity it cannot
+reproduce is torch.sum's fp32 rounding, which depends on the host's vector width.  An ulp in that sum moves
+every cdf entry by at most an ulp, and a draw by  ulp(1) * (bin width) / (bin probability): the test bounds each
+draw by exactly that conditioning (CDF_ULPS ulps of the cdf), i.e. it asks for ulp-level agreement of the CDF,
+and reports how many draws are bit-identical (all draws of every ray whose sum rounds the same way).  sample_pdf
+is also piecewise -- bin choice by searchsorted, `denom < eps -> 1` (rendering.py:33-42) -- so a draw within those
+few ulps of a breakpoint may fall on either side; `_admissible_error` spells the rule out.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+CDF_ULPS = 2.0
+ULP1 = 2.0 ** -24
+EPS = 1e-5
+
+
+def _hip_sample(z, w, u, I):
+    from nerf_fl_amd import _lib
+    dev = "cuda:0"
+    R, S = z.shape
+    zd, wd = z.to(dev).contiguous(), w.to(dev).contiguous()
+    z_fine = torch.empty(R, S + I, device=dev)
+    smp = torch.empty(R, I, device=dev)
+    if u is None:
+        u_row, ud = torch.linspace(0, 1, I, device=dev), None
+    else:
+        u_row, ud = None, u.to(dev).contiguous()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    _lib.check(_lib.lib().nfl_sample_pdf(p(zd), p(wd), p(ud), p(u_row), R, S, I, p(z_fine), p(smp),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nfl_sample_pdf")
+    torch.cuda.synchronize()
+    return z_fine.cpu(), smp.cpu()
+
+
+def _kernel_model(z, w, u):
+    """The arithmetic nfl_sample.hip performs, restated with numpy (fp64 sum and scan rounded once, everything else
+    fp32 operation by operation).  Used on the CPU to check this file's acceptance rule without a GPU."""
+    z, w, u = z.numpy(), w.numpy(), u.numpy()
+    R, S = z.shape
+    eps = np.float32(EPS)
+    ww = (w[:, 1:-1] + eps).astype(np.float32)
+    total = ww.astype(np.float64).sum(1).astype(np.float32)
+    pdf = (ww / total[:, None]).astype(np.float32)
+    cdf = np.concatenate([np.zeros((R, 1), np.float32), np.cumsum(pdf.astype(np.float64), 1).astype(np.float32)], 1)
+    mids = (np.float32(0.5) * (z[:, :-1] + z[:, 1:])).astype(np.float32)
+    M = S - 2
+    out = np.zeros_like(u)
+    for r in range(R):
+        lo = np.searchsorted(cdf[r], u[r], side="right")
+        below, above = np.maximum(lo - 1, 0), np.minimum(lo, M)
+        c0, c1, b0, b1 = cdf[r][below], cdf[r][above], mids[r][below], mids[r][above]
+        den = (c1 - c0).astype(np.float32)
+        den[den < eps] = 1
+        out[r] = (b0 + ((u[r] - c0) / den).astype(np.float32) * (b1 - b0)).astype(np.float32)
+    return torch.from_numpy(out)
+
+
+def _admissible_error(z, w, u, smp):
+    """For every draw: distance of `smp` to the nearest value the reference's algorithm can return when its cdf is
+    perturbed by at most CDF_ULPS ulps, divided by that value's own error bound (<= 1 means accepted).
+    sample_pdf is piecewise: a draw picks the bin with cdf[j] <= u < cdf[j+1] (searchsorted right=True, then the
+    clamps of rendering.py:34-35), and a bin narrower than eps gets denominator 1 (rendering.py:41-42).  A draw within
+    a few ulps of a breakpoint, or a bin within a few ulps of eps, may legitimately fall on either side; inside a
+    branch the result moves by  delta * width / den  for a cdf error delta (plus the cancellation in den = c1 - c0)."""
+    zz, ww = z.double(), (w[:, 1:-1] + EPS).double()
+    mids = 0.5 * (zz[:, :-1] + zz[:, 1:])                                    # (R, M+1)
+    pdf = ww / ww.sum(1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), pdf.cumsum(1)], 1)         # (R, M+1)
+    M = pdf.shape[1]
+    ud, sd = u.double(), smp.double()
+    delta = CDF_ULPS * ULP1
+    j0 = (torch.searchsorted(cdf.contiguous(), ud.contiguous(), right=True) - 1).clamp(min=0)      # bin of the draw, 0..M
+    best = torch.full_like(sd, float("inf"))
+    for dj in (-1, 0, 1):
+        j = (j0 + dj).clamp(0, M)
+        top = j == M                                   # clamped: below = above = M, the sample is the last mid-point
+        jn = (j + 1).clamp(max=M)
+        c0, c1 = cdf.gather(1, j), cdf.gather(1, jn)
+        b0, b1 = mids.gather(1, j), mids.gather(1, jn)
+        reach = (ud >= c0 - delta) & ((ud <= c1 + delta) | top)
+        den = c1 - c0
+        for branch in ("keep", "one"):
+            if branch == "keep":
+                valid = reach & (den >= EPS - delta) & ~top
+                d = den.clamp(min=EPS - delta)
+            else:
+                valid = reach & ((den < EPS + delta) | top)
+                d = torch.ones_like(den)
+            cand = b0 + (ud - c0) / d * (b1 - b0)
+            # cdf error delta in (u - c0) and 2 * delta in den = c1 - c0 (|u - c0| <= den + delta), then fp32 rounding
+            tol = 3 * delta * (b1 - b0).abs() / d + 8 * ULP1 * cand.abs() + 1e-7
+            ratio = torch.where(valid, (sd - cand).abs() / tol, torch.full_like(sd, float("inf")))
+            best = torch.minimum(best, ratio)
+    return best
+
+
+def _check(z, w, u, smp, exp, label):
+    ratio = _admissible_error(z, w, u, smp)
+    exact = float((smp == exp).float().mean())
+    print(f"sample_pdf[{label}]: {100 * exact:.2f}% of {smp.numel()} draws bit-identical to the reference, "
+          f"worst |err| {(smp - exp).abs().max().item():.3e}, worst distance/bound {float(ratio.max()):.3f}")
+    assert float(_admissible_error(z, w, u, exp).max()) <= 1.0, "the reference's own output must satisfy the rule"
+    bad = (ratio > 1.0).nonzero()
+    assert bad.numel() == 0, f"{bad.shape[0]} draws further than {CDF_ULPS} cdf-ulps from the reference, e.g. {bad[:4].tolist()}"
+    assert exact >= 0.85, "draws of rays whose normalising sum rounds the same way must be bit-identical"
+
+
+def _inputs(mode):
+    cfg, a = gu.load("g3b_sample_pdf_coarse")
+    I = cfg["n_importance"]
+    z, w = a["z_coarse"], a["weights_coarse"]
+    u = torch.linspace(0, 1, I).expand(z.shape[0], I).contiguous() if mode == "det" else a["u"]
+    return a, I, z, w, u
+
+
+@pytest.mark.parametrize("mode", ["det", "rnd"])
+def test_acceptance_rule_on_kernel_model_cpu(mode):
+    """No GPU: the numpy restatement of the kernel's arithmetic passes the same rule the GPU test applies (keeps the
+    rule itself honest, and pins what the kernel is meant to compute)."""
+    a, I, z, w, u = _inputs(mode)
+    _check(z, w, u, _kernel_model(z, w, u), a[mode], "model/" + mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["det", "rnd"])
+def test_sample_pdf_edge_cases(mode):
+    a, I, z, w, u = _inputs(mode)
+    z_fine, smp = _hip_sample(z, w, None if mode == "det" else u, I)
+    _check(z, w, u, smp, a[mode], mode)
+    model = _kernel_model(z, w, u)
+    print(f"   vs the numpy model of the kernel: {100 * float((smp == model).float().mean()):.2f}% bit-identical")
+    # concat + sort (rendering.py:272): exactly the sorted multiset of the coarse depths and the kernel's own draws
+    assert torch.equal(z_fine, torch.sort(torch.cat([z, smp], 1), 1)[0])
+    # rows all of whose draws are bit-identical must give the reference's merged row bit for bit
+    same = (smp == a[mode]).all(1)
+    assert same.sum() >= 24
+    assert torch.equal(z_fine[same], a[f"z_fine_{mode}"][same])
+
+
+@pytest.mark.gpu
+def test_sample_pdf_empty_rays_are_uniform():
+    """Rays without any interior weight (rows 8..11 and 16..19 of the fixture): the pdf is uniform, so the
+    deterministic draws run evenly from the first to the last mid-point -- a closed form to hold the kernel to."""
+    a, I, z, w, u = _inputs("det")
+    _, smp = _hip_sample(z, w, None, I)
+    for r in list(range(8, 12)) + list(range(16, 20)):
+        mids = 0.5 * (z[r, :-1] + z[r, 1:])
+        lin = mids[0] + (mids[-1] - mids[0]) * torch.linspace(0, 1, I)
+        assert (smp[r] - lin).abs().max().item() <= 2e-5
