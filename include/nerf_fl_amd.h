@@ -41,7 +41,8 @@ enum {
 
 /* Arithmetic used inside the MLP (everything outside the matrix products --
  * positional encoding, activations, compositing, sampling -- is always fp32). */
-#define NFL_STATUS_NONFINITE 1
+#define NFL_STATUS_NONFINITE 1   /* a composited per-ray output of a render pass was NaN / inf                        */
+#define NFL_STATUS_RANGE 2       /* a weight or an activation exceeded fp16's range (|x| > 65504) inside the fused MLP */
 
 enum {
     NFL_PREC_F16X3 = 0,   /* fp16 MFMA, operands split hi+lo, 3 products: ~2^-21 relative, fp32-class (default) */
@@ -95,9 +96,10 @@ size_t nfl_param_count(const nfl_field_desc* desc);
 
 /* Re-pack the current fp32 parameters into MFMA fragment order (run after every
  * optimizer step; ~2.4 MB read, <=4.8 MB written). h_plan is the same table in
- * HOST memory (used only to size the launch). */
+ * HOST memory (used only to size the launch).  d_status (device int32, may be NULL): NFL_STATUS_RANGE is OR-ed in
+ * when a weight does not fit fp16's range. */
 int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_params* params,
-                   void* d_packed, size_t packed_bytes, void* stream);
+                   void* d_packed, size_t packed_bytes, int32_t* d_status, void* stream);
 
 /* ---- one rendering pass (reference: inference(), rendering.py:83-226) --- */
 
@@ -147,11 +149,12 @@ typedef struct nfl_pass_args {
        computed by the caller exactly as barf_weight(freq, epoch) does; NULL = plain PosEmbedding     */
     const float* d_pe_w_xyz;    /* (n_emb_xyz) or NULL                                                   */
     const float* d_pe_w_dir;    /* (n_emb_dir) or NULL                                                   */
-    /* optional status word (device, int32, never cleared by the library): bit NFL_STATUS_NONFINITE is OR-ed in when a
-       composited per-ray output of this pass is not finite.  The MLP multiplies fp16 operands: an activation or a
-       weight beyond fp16's range (|x| > 65504), which the fp32 reference would carry, turns into NaN here (hi = inf,
-       lo = -inf) and poisons its ray -- the ABI's range limit; this word is how a caller detects it
-       without scanning the outputs. */
+    /* optional status word (device, int32, never cleared by the library): NFL_STATUS_* bits are OR-ed in.  The MLP
+       multiplies fp16 operands: an activation or a weight beyond fp16's range (|x| > 65504), which the fp32 reference
+       would carry, cannot be represented here (hi = inf, lo = -inf; the matrix cores then produce NaNs that the next
+       relu turns into zeros, so the outputs may even look plausible) -- the ABI's range limit.  The
+       kernels track the largest fp16 operand they form and report NFL_STATUS_RANGE; this word is how a caller learns
+       of it without scanning anything. */
     int32_t* d_status;
     /* used by nfl_field_forward only (leave NULL / 0 otherwise) */
     const float* d_embedded;

@@ -13,6 +13,8 @@ NFL_ABI_VERSION = 5
 NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
+NFL_STATUS_NONFINITE = 1
+NFL_STATUS_RANGE = 2
 NFL_NUM_LAYERS = 19
 
 # layer slot -> state_dict prefix (reference models/nerf.py:121-151)
@@ -108,7 +110,8 @@ SYMBOLS = [
     ("nfl_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int, C.c_void_p, C.c_size_t]),
     ("nfl_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int]),
     ("nfl_param_count", C.c_size_t, [C.POINTER(FieldDesc)]),
-    ("nfl_pack_field", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FieldParams), C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("nfl_pack_field", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FieldParams), C.c_void_p, C.c_size_t, C.c_void_p,
+                                 C.c_void_p]),
     ("nfl_render_pass", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassArgs), C.c_void_p]),
     ("nfl_sample_pdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -19,6 +19,7 @@ struct PackArgs {
     const NflPlan* plan;        // device copy
     nfl_field_params params;
     char* out;                  // packed buffer
+    int32_t* status;            // NFL_STATUS_RANGE is OR-ed in when a weight exceeds fp16's range; may be null
 };
 
 __global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
@@ -80,6 +81,12 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
         }
     }
     char* dst = a.out + (size_t)gks * P.ks_bytes + lane * 16;
+    if (P.elem == 0 && a.status) {
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad |= !(fabsf(w[j]) <= 65504.f);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.status, NFL_STATUS_RANGE);
+    }
     if (P.elem == 0) {
         h8 hi, lo;
 #pragma unroll
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
 }
 
 extern "C" int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_params* params,
-                              void* d_packed, size_t packed_bytes, void* stream) {
+                              void* d_packed, size_t packed_bytes, int32_t* d_status, void* stream) {
     const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
     if (!hp || !d_plan || !params || !d_packed || hp->magic != NFL_PLAN_MAGIC) return NFL_EINVAL;
     if (packed_bytes < (size_t)hp->packed_bytes) return NFL_ESMALL;
@@ -110,6 +117,7 @@ extern "C" int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_
     a.plan = static_cast<const NflPlan*>(d_plan);
     a.params = *params;
     a.out = static_cast<char*>(d_packed);
+    a.status = d_status;
     hipLaunchKernelGGL(nfl_pack_kernel, dim3(hp->total_ks + hp->n_rt), dim3(64), 0,
                        static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;

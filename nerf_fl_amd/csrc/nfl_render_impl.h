@@ -228,6 +228,10 @@ struct NflRing {
     unsigned long long t_wait = 0, t_bar = 0;   // cycles in consume(): DMA wait / workgroup barrier
 #endif
     int n_off0, n_off1;   // table entries of chunk c_issue, fetched one step ahead (no LDS latency after the barrier)
+    // Not ring state, but it travels with the ring through every layer: per-lane running maximum (packed u16 pair) of
+    // the |fp16 bit patterns| the activation epilogues have formed.  >= 0x7c00 at the end of the kernel means an
+    // activation left fp16's range (the conversion gave inf); reported through nfl_pass_args::d_status.
+    unsigned ovf = 0;
 
     NFL_DEV void begin_issue() {
         i_nbytes = n_off1 - n_off0;
@@ -422,6 +426,7 @@ struct NflActEpi {
     char* const (&mstash)[NCB];      // relu-mask records of the lane's segments (training forward)
     const int mword;                 // mask word of this tile
     unsigned (&mq)[NCB][4];          // the words of the current group of four tiles: one dwordx4 store per group
+    unsigned& ovf;                   // NflRing::ovf
     h8 tmp[NCB];
     unsigned m32[NCB];
 
@@ -447,6 +452,10 @@ struct NflActEpi {
                 hi = nfl_pack2<_Float16>(x0, x1);
             }
             reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
+            {   // range tracking: after relu the halves are non-negative, so their bit patterns order like the values
+                const unsigned mag = RELU ? hi : (hi & 0x7fff7fffu);
+                asm("v_pk_max_u16 %0, %0, %1" : "+v"(ovf) : "v"(mag));
+            }
             if (STASH) {        // the fp16 hi operand IS the stashed activation
                 reinterpret_cast<unsigned(&)[4]>(tmp[cb])[j / 2] = hi;
 #ifdef NFL_ABL_NOSTASHST
@@ -515,7 +524,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         constexpr int frag0 = (i % TPC) * NK;
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         if constexpr (i > 0) {
-            NflActEpi<NP, NCB, RELU, STASH, NOUT, (i - 1) & 3> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1, mq};
+            NflActEpi<NP, NCB, RELU, STASH, NOUT, (i - 1) & 3> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1, mq, ring.ovf};
             nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
         } else {
             NflNoEpi epi;
@@ -524,7 +533,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         // pieces the k-loop of this chunk did not get to
         if (i % TPC == TPC - 1 || i == NRT - 1) ring.template pieces<((i % TPC) + 1) * NK, Ring::MAXP>();
     });
-    NflActEpi<NP, NCB, RELU, STASH, NOUT, (NRT - 1) & 3> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1, mq};
+    NflActEpi<NP, NCB, RELU, STASH, NOUT, (NRT - 1) & 3> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1, mq, ring.ovf};
     last.all();
     rt += NRT;
 }
@@ -1047,6 +1056,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         NFL_STAMP(17);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two prefetched chunks before exit
+    if (a.d_status) {      // an activation beyond fp16's range: the conversion gave inf (0x7c00) -- header, d_status
+        const bool bad = (ring.ovf & 0xffffu) >= 0x7c00u || (ring.ovf >> 16) >= 0x7c00u;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.d_status, NFL_STATUS_RANGE);
+    }
 #ifdef NFL_STAMPS
     NFL_STAMP(18);
     t_acc[14] = ring.t_wait;

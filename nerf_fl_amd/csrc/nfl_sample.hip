@@ -5,11 +5,13 @@
 // depths and per-row sort).  Per ray: ~30 small ATen kernels become one wave doing
 //   1. w = weights[1:-1] + 1e-5, wave reduction for the sum, pdf = w / sum
 //   2. cdf = [0, inclusive wavefront prefix scan of pdf]      (shuffle scan, 64 bins per pass)
-//      Both the sum and the scan accumulate in fp64 and round to fp32 once per output.  For the scan that is
-//      exactly what the reference computes on the CPU (ATen's cumsum accumulates fp32 inputs in double), and because
-//      the pdf entries lie in [2^-23, 1] every fp64 partial sum is exact, so the parallel scan order cannot show: the
-//      cdf is bit-identical to torch.cumsum's for the same pdf.  torch.sum's fp32 result depends on the host's vector
-//      width; the correctly rounded sum used here is within an ulp or two of any of them.
+//      The arithmetic is the reference's CPU arithmetic, operation for operation, so that for the same coarse weights
+//      the draws are bit-identical to torch's (tests/test_sample_pdf_gpu.py) -- which matters because sample_pdf is
+//      discontinuous: a bin whose probability is within rounding of `eps` flips between two formulas (rendering.py:41-42).
+//        - the sum follows ATen's fp32 CPU reduction order (SumKernel.cpp: 8-lane vectors, 4 interleaved vector
+//          accumulators, the scalar tail, then the 8 partials in order), reproduced here by 32 lanes + one serial lane;
+//        - the scan accumulates in fp64 and rounds to fp32 once per output, as ATen's CPU cumsum does; the pdf entries
+//          lie in [2^-23, 1], so every fp64 partial sum is exact and the parallel scan order cannot show.
 //   3. for every u: count of cdf <= u by binary search in LDS (searchsorted right=True),
 //      clamp, gather, lerp; zero-width bins (< eps) get denominator 1
 //   4. merge with the coarse depths by rank counting in LDS (stable; the result is the
@@ -40,12 +42,36 @@ __global__ __launch_bounds__(256) void nfl_sample_pdf_kernel(SampleArgs a) {
     const float* wr = a.w + (size_t)ray * S + 1;
     const float eps = 1e-5f;
 
-    // 1. sum of (w + eps): fp32 addends (as the reference forms them), fp64 accumulation, one rounding
-    double part = 0.0;
-    for (int j = lane; j < M; j += 64) part += (double)(wr[j] + eps);
+    // 1. sum of (w + eps) in ATen's CPU order.  Lane (k = lane / 8, v = lane % 8), k < 4, owns vector accumulator k,
+    // element v: it adds the elements of vectors k, k + 4, k + 8, ... in order; left-over vectors go to accumulator 0.
+    float total;
+    if (M < 8) {           // ATen's scalar path for rows shorter than a vector: 4 interleaved scalar accumulators
+        float acc = 0.f;
+        const int nq = M >> 2;
+        if (lane < 4)
+            for (int i = 0; i < nq; ++i) acc += wr[(i << 2) + lane] + eps;
+        if (lane == 0)
+            for (int j = nq << 2; j < M; ++j) acc += wr[j] + eps;
+        const float a1 = __shfl(acc, 1), a2 = __shfl(acc, 2), a3 = __shfl(acc, 3);
+        total = __shfl(((acc + a1) + a2) + a3, 0);
+    } else {
+        const int nv = M >> 3, nfull = nv >> 2;          // whole 8-lane vectors; groups of 4 vectors
+        const int k = lane >> 3, v = lane & 7;
+        float acc = 0.f;
+        if (lane < 32) {
+            for (int i = 0; i < nfull; ++i) acc += wr[((i << 2) + k) * 8 + v] + eps;
+            if (k == 0)
+                for (int i = nfull << 2; i < nv; ++i) acc += wr[i * 8 + v] + eps;
+        }
+        // accumulator 0 += 1, += 2, += 3 (lanes 0..7)
+        const float a1 = __shfl(acc, (lane & 7) + 8), a2 = __shfl(acc, (lane & 7) + 16), a3 = __shfl(acc, (lane & 7) + 24);
+        acc = ((acc + a1) + a2) + a3;
+        float fin = 0.f;
+        for (int j = nv << 3; j < M; ++j) fin += wr[j] + eps;           // scalar tail
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
-    const float total = (float)part;
+        for (int q = 0; q < 8; ++q) fin += __shfl(acc, q);              // the 8 partials, in order
+        total = fin;
+    }
 
     // 2. cdf by wavefront inclusive scan, 64 bins per pass (fp64 partial sums, see the header)
     double run = 0.0;

@@ -17,7 +17,8 @@ Randomness: the reference draws rand_like (jitter), randn_like (density noise,
 even when noise_std == 0), rand (importance u), randn_like (fine noise) in that
 order.  The same draws are made here with torch's
 generator on the rays' device, unless the caller injects them through the
-build-defined kwargs `perturb_rand`, `noise_coarse`, `u`, `noise_fine`.
+build-defined kwargs `perturb_rand`, `noise_coarse`, `u`, `noise_fine`; `z_fine` (R, N_samples + N_importance)
+injects the sorted fine depths themselves (the importance sampler is then skipped).
 
 Numerical range: the fused MLP multiplies fp16 operands (split hi+lo), so activations and weights must stay
 within fp16's range (|x| <= 65504); beyond it the affected rays come out as NaN where the fp32 reference stays
@@ -76,9 +77,13 @@ def check_status(device=None):
         bits = int(w.item())
         if bits:
             w.zero_()
-            raise FloatingPointError(
-                f"nerf_fl_amd: a render pass on {k} produced non-finite outputs: an activation or weight exceeded "
-                "fp16's range (|x| > 65504) inside the fused MLP (see INTEGRATION.md, 'Numerical range')")
+            what = []
+            if bits & _lib.NFL_STATUS_RANGE:
+                what.append("a weight or an activation exceeded fp16's range (|x| > 65504) inside the fused MLP")
+            if bits & _lib.NFL_STATUS_NONFINITE:
+                what.append("a composited per-ray output was not finite")
+            raise FloatingPointError(f"nerf_fl_amd: render pass on {k}: " + "; ".join(what)
+                                     + " (see INTEGRATION.md, 'Numerical range')")
 
 
 def _stream():
@@ -156,7 +161,7 @@ class _PackedField:
         if bp["key"] != self.key:
             fp, _keep = self._field_params()
             _lib.check(L.nfl_pack_field(bp["h"], _ptr(bp["d"]), C.byref(fp), _ptr(bp["packed"]), bp["nbytes"],
-                                        _stream()), "nfl_pack_field(bwd)")
+                                        C.c_void_p(0), _stream()), "nfl_pack_field(bwd)")
             bp["key"] = self.key
         return bp
 
@@ -184,7 +189,8 @@ class _PackedField:
             return
         fp, _keep = self._field_params()
         _lib.check(_lib.lib().nfl_pack_field(self.h_plan, _ptr(self.d_plan), C.byref(fp), _ptr(self.packed),
-                                             self.packed_bytes, _stream()), "nfl_pack_field")
+                                             self.packed_bytes, _ptr(_status_word(self.device)), _stream()),
+                   "nfl_pack_field")
         self.key = key
 
 
@@ -332,9 +338,12 @@ def _forward(cfg, rays, a_emb, t_emb, train):
                                use_t=False, n=S)
     if I > 0:
         F = S + I
-        z_fine = torch.empty(R, F, dtype=torch.float32, device=dev)
-        _lib.check(_lib.lib().nfl_sample_pdf(_ptr(oc["z"]), _ptr(oc["weights"]), _ptr(cfg["u"]), _ptr(cfg["u_row"]),
-                                             R, S, I, _ptr(z_fine), C.c_void_p(0), _stream()), "nfl_sample_pdf")
+        if cfg["z_fine"] is not None:        # injected fine depths (build-defined kwarg `z_fine`): the sampler is skipped
+            z_fine = cfg["z_fine"]
+        else:
+            z_fine = torch.empty(R, F, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().nfl_sample_pdf(_ptr(oc["z"]), _ptr(oc["weights"]), _ptr(cfg["u"]), _ptr(cfg["u_row"]),
+                                                 R, S, I, _ptr(z_fine), C.c_void_p(0), _stream()), "nfl_sample_pdf")
         use_t = cfg["use_t"]
         of = _run_pass(f_f, rays, F, z=z_fine, noise=cfg["noise_f"], noise_std=cfg["noise_std"], a_emb=a_emb,
                        t_emb=t_emb if use_t else None, view_dir=cfg["view_dir"], white_back=cfg["white_back"],
@@ -490,7 +499,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         cfg = dict(S=S, I=I, use_disp=bool(use_disp), perturb=float(perturb), noise_std=float(noise_std),
                    white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
                    view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
-                   use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None)
+                   use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None)
         if getattr(models["coarse"], "refine_pose", False):
             # BARF (reference rendering.py:105-108, 235-238): coarse-to-fine weights of both encodings
             epoch = kwargs.get("current_epoch")
@@ -517,6 +526,8 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         if I > 0:
             if S < 3:
                 raise ValueError("N_samples must be >= 3 when N_importance > 0")
+            if kwargs.get("z_fine") is not None:
+                cfg["z_fine"] = _f32c(kwargs["z_fine"], "z_fine", (R, F))
             if perturb == 0:
                 cfg["u_row"] = _linspace(I, dev)
             else:

@@ -310,11 +310,25 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
         p.requires_grad_(grads)
 
     torch.manual_seed(1000 + seed + R + S + I)     # the captured draws are part of the fixture: keep them reproducible
-    with CaptureRandom() as cap:
-        ctx = torch.enable_grad() if grads else torch.no_grad()
-        with ctx:
-            res = render_rays(models, embeddings, rays, ts, S, use_disp, perturb, noise_std, I,
-                              32768, white_back, test_time, **kwargs)
+    sorted_rows, orig_sort = [], torch.sort
+
+    def sort_spy(*a, **k):         # the reference sorts once: the merged fine depths (rendering.py:272)
+        out = orig_sort(*a, **k)
+        sorted_rows.append(out[0].detach().clone())
+        return out
+
+    torch.sort = sort_spy
+    try:
+        with CaptureRandom() as cap:
+            ctx = torch.enable_grad() if grads else torch.no_grad()
+            with ctx:
+                res = render_rays(models, embeddings, rays, ts, S, use_disp, perturb, noise_std, I,
+                                  32768, white_back, test_time, **kwargs)
+    finally:
+        torch.sort = orig_sort
+    if I > 0:
+        assert len(sorted_rows) == 1 and tuple(sorted_rows[0].shape) == (R, S + I)
+        arrays["z_fine"] = sorted_rows[0]          # the depths the reference's fine pass used
     cfg["rng_order"] = [t for t, _ in cap.log]
     cfg["keys"] = list(res.keys())
     for i, (tag, val) in enumerate(cap.log):

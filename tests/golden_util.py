@@ -104,3 +104,79 @@ def oracle_kwargs(cfg, arrays):
         kw["pe_w_xyz"] = orc.barf_weights(spec_c.n_emb_xyz, cfg["barf_epoch"])
         kw["pe_w_dir"] = orc.barf_weights(spec_c.n_emb_dir, cfg["barf_epoch"])
     return (spec_c, P_c, spec_f, P_f), kw
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Conditioning of the importance sampling of a fixture (which rays an end-to-end comparison can hold to 1e-4)
+# ----------------------------------------------------------------------------------------------------------------
+SAMPLE_EPS = 1e-5
+
+
+def sampling_conditioning(z_coarse, w_coarse, u, delta_w=1e-7):
+    """Per ray: the largest depth interval within which one of its importance draws may legitimately land when the
+    coarse weights are perturbed at the level two correct implementations differ by (returns (R,) tensor, fp64).
+
+    sample_pdf (rendering.py:7-46) is discontinuous in its inputs: `denom[denom < eps] = 1` switches formula for bins
+    whose probability is within rounding of eps -- and (w + eps) / sum with eps = 1e-5 puts EVERY empty bin of a nearly
+    opaque ray (sum ~ 1) right at that switch, where the float rounding of two cdf entries near 1 (ulp 6e-8..1.2e-7
+    against a difference of 1e-5) decides; and searchsorted flips bins at the breakpoints.  Coarse weights that agree
+    to 1e-6 (far inside the 1e-4 parity bar) therefore do not imply equal fine depths on such rays: the reference run
+    on another device, or with another summation order, differs from itself there.  And the pdf is (w + eps) / sum:
+    on a nearly EMPTY ray (sum ~ 1e-3) an absolute weight difference of 6e-8 is a pdf difference of 6e-5.
+    This function derives, from the reference's own coarse outputs, how far each ray's draws may move when the
+    coarse weights agree to `delta_w` absolute per entry (two fp32-class implementations: ~1e-7):
+      delta_cdf = 4 delta_w / sum: uncertainty of a cdf entry relative to u (a few non-cancelling pdf entries),
+      delta_den = max(2.5e-7, 2 delta_w / sum): uncertainty of a bin's probability as computed (one pdf entry, and
+                  the fp32 rounding of cdf[j+1] - cdf[j] near 1).
+    The end-to-end parity test requires every fine depth of the HIP path to lie within this interval of the
+    reference's (tests/test_parity_gpu.py); field and compositing are pinned at 1e-4 on ALL rays with the reference's
+    depths injected (render_rays(..., z_fine=...)), and the sampler itself bit for bit on identical inputs
+    (tests/test_sample_pdf_gpu.py)."""
+    zz, ww = z_coarse.double(), (w_coarse[:, 1:-1] + SAMPLE_EPS).double()
+    mids = 0.5 * (zz[:, :-1] + zz[:, 1:])
+    total = ww.sum(1, keepdim=True)
+    pdf = ww / total
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), pdf.cumsum(1)], 1)
+    M = pdf.shape[1]
+    ud = u.double()
+    delta_cdf = 4.0 * delta_w / total                                    # (R, 1)
+    delta_den = (2.0 * delta_w / total).clamp(min=2.5e-7)
+    j0 = (torch.searchsorted(cdf.contiguous(), ud.contiguous(), right=True) - 1).clamp(min=0)
+    lo = torch.full_like(ud, float("inf"))
+    hi = torch.full_like(ud, float("-inf"))
+    for dj in (-1, 0, 1):
+        j = (j0 + dj).clamp(0, M)
+        top = j == M
+        jn = (j + 1).clamp(max=M)
+        c0, c1 = cdf.gather(1, j), cdf.gather(1, jn)
+        b0, b1 = mids.gather(1, j), mids.gather(1, jn)
+        reach = (ud >= c0 - delta_cdf) & ((ud <= c1 + delta_cdf) | top)
+        den = c1 - c0
+        width = (b1 - b0).abs()
+        frac_num = (ud - c0).clamp(min=0.0)
+        for branch in ("keep", "one"):
+            if branch == "keep":
+                valid = reach & (den >= SAMPLE_EPS - delta_den) & ~top
+                d = den.clamp(min=SAMPLE_EPS - delta_den)
+            else:
+                valid = reach & ((den < SAMPLE_EPS + delta_den) | top)
+                d = torch.ones_like(den)
+            cand = b0 + (frac_num / d).clamp(max=1.0) * (b1 - b0)
+            # cdf[0] is exactly 0 in every implementation: a draw in the first bin has no breakpoint uncertainty
+            d_c0 = torch.where(j == 0, torch.zeros_like(den), delta_cdf.expand_as(den))
+            spread = (d_c0 + frac_num / d * delta_den).clamp(max=d) / d * width
+            lo = torch.where(valid, torch.minimum(lo, cand - spread), lo)
+            hi = torch.where(valid, torch.maximum(hi, cand + spread), hi)
+    return (hi - lo).clamp(min=0).max(dim=1)[0]
+
+
+def fixture_conditioning(cfg, arrays, **deltas):
+    """sampling_conditioning of a render fixture (None when it has no fine pass), from the reference's own outputs."""
+    if cfg["I"] == 0:
+        return None
+    rays = arrays["rays"]
+    rnd = random_inputs(cfg, arrays)
+    z = orc.coarse_depths(rays[:, 6:7], rays[:, 7:8], cfg["S"], cfg["use_disp"], cfg["perturb"], rnd["perturb_rand"])
+    R, I = rays.shape[0], cfg["I"]
+    u = rnd["u"] if cfg["perturb"] > 0 else torch.linspace(0, 1, I).expand(R, I)
+    return sampling_conditioning(z, arrays["out.weights_coarse"], u, **deltas)

@@ -45,6 +45,8 @@ def hip_render(specs, rays, kw, precision="f16x3", field_raw=False):
         extra["t_embedded"] = kw["t_emb"].to(DEV)
     if kw.get("view_dir") is not None:
         extra["view_dir"] = kw["view_dir"].to(DEV)
+    if kw.get("z_fine") is not None:       # fine depths of the reference run (fixture array `z_fine`)
+        extra["z_fine"] = kw["z_fine"].to(DEV)
     if not kw.get("output_transient", True):
         extra["output_transient"] = False
     if field_raw:

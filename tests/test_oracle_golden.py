@@ -62,7 +62,9 @@ def test_render_forward(name):
     (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
     kw.pop("barf_epoch", None)
     with torch.no_grad():
-        res = orc.render_rays(spec_c, P_c, spec_f, P_f, a["rays"], **kw)
+        res = orc.render_rays(spec_c, P_c, spec_f, P_f, a["rays"], return_z=cfg["I"] > 0, **kw)
+    if cfg["I"] > 0:        # the merged, sorted fine depths the reference's fine pass used (captured by the generator)
+        assert (res.pop("_z_fine") - a["z_fine"]).abs().max().item() <= 1e-6
     assert list(res.keys()) == cfg["keys"], "dict key order must match the reference"
     for k in cfg["keys"]:
         exp = a["out." + k]

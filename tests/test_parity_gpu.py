@@ -14,37 +14,34 @@ RENDER = [n for n in gu.golden_names("g") if n[:2] in ("g4", "g5", "g6", "g7", "
           or n.startswith(("g10", "g12_stoch_base", "g12_stoch_nerfw", "g13", "g14_barf_e2", "g15", "g16", "g17"))]
 
 
-# Inverse-CDF sampling is ill-conditioned inside bins whose coarse weight is exactly zero: their pdf is
-# eps/sum ~ 1e-5, so a 1-ulp (6e-8) difference in the running CDF -- the reference's own CPU result
-# depends on the vector width of torch.sum -- moves a sample drawn there by ~1e-2 of a bin (|dz| ~ 6e-4),
-# which changes that sample's weight and its ray's opacity/depth by a few 1e-4.  With random u about one
-# draw in 10^4 lands in such a bin.  Those draws are tolerated in the STOCHASTIC fixtures only: at most
-# OUTLIER_FRAC of the per-sample entries and OUTLIER_RAYS of the rays may exceed the tolerance, and
-# then by < 1e-2.  Deterministic fixtures (perturb == 0) are held to 1e-4 everywhere.
-OUTLIER_FRAC = 2.5e-4
-OUTLIER_RAYS = 0.02
+# Importance sampling (rendering.py:7-46) is discontinuous / ill-conditioned in the coarse weights: see
+# golden_util.sampling_conditioning.  With trained-like weights (empty space behind the surface, opacity ~ 1) a coarse
+# weight that differs by 1e-7 -- three orders inside the parity bar -- moves some fine depths by 1e-4..1e-3 (the u = 1
+# draw flips between the last bin and the clamp; a draw in a bin of probability 2e-5 moves by 1e-7 / 2e-5 of a bin), and
+# a trained field is steep enough (sin(512 z) features) for that to change a per-sample output by 1e-1.  The reference
+# differs from ITSELF by as much between two devices.  Three comparisons per fixture therefore:
+#   * test_render_at_reference_depths: the fine depths of the reference run (fixture array `z_fine`) are injected, so
+#     field + compositing are held to 1e-4 on EVERY ray and EVERY output, stochastic fixtures included, no allowance;
+#   * tests/test_sample_pdf_gpu.py: on identical inputs the HIP sampler's draws are bit-identical to the reference's;
+#   * test_render_vs_golden (here): end to end through the HIP sampler.  The coarse pass: 1e-4 everywhere.  Every fine
+#     depth must lie within what the reference's own conditioning allows for coarse weights agreeing to 1e-7 absolute
+#     (golden_util.sampling_conditioning); on rays whose depths reproduce the reference's to Z_SAME every output must
+#     meet 1e-4; on the others the per-ray outputs must agree to LOOSE (per-sample arrays shift by one position when a
+#     draw changes bins, and are not compared index by index there).
+Z_SAME = 1e-5
+LOOSE = 2e-2
 PER_SAMPLE = ("weights_fine", "transient_sigmas")
 
 
-def _compare(name, got, exp, keys, tol, stochastic=False):
-    worst = {}
-    bad = {}
+def _worst(got, exp, keys, rows=None):
+    out = {}
     for k in keys:
         assert got[k].shape == exp[k].shape, k
-        err = (got[k] - exp[k]).abs()
-        worst[k] = err.max().item()
-        if stochastic and k.endswith("_fine") or (stochastic and k in PER_SAMPLE):
-            if k in PER_SAMPLE:
-                n_out, lim = int((err > tol).sum()), OUTLIER_FRAC * err.numel()
-            else:
-                n_out = int((err.reshape(err.shape[0], -1).max(1)[0] > tol).sum())
-                lim = max(1.0, OUTLIER_RAYS * err.shape[0])
-            if n_out > lim or worst[k] > 1e-2:
-                bad[k] = (worst[k], n_out)
-        elif not worst[k] <= tol:
-            bad[k] = worst[k]
-    assert not bad, f"{name}: max abs err over tolerance {tol}: {bad} (all: {worst})"
-    return worst
+        d = (got[k] - exp[k]).abs()
+        if rows is not None:
+            d = d[rows]
+        out[k] = d.max().item() if d.numel() else 0.0
+    return out
 
 
 @pytest.mark.parametrize("name", RENDER)
@@ -52,10 +49,49 @@ def test_render_vs_golden(name):
     import gpu_util
     cfg, a = gu.load(name)
     specs, kw = gu.oracle_kwargs(cfg, a)
-    got = gpu_util.hip_render(specs, a["rays"], kw, precision="f16x3")
+    got = gpu_util.hip_render(specs, a["rays"], kw, precision="f16x3", field_raw=cfg["I"] > 0)
+    z_hip = got.pop("_z_fine", None)
+    for k in ("_field_raw_coarse", "_field_raw_fine"):
+        got.pop(k, None)
     assert list(got.keys()) == cfg["keys"], "result keys / order must match the reference"
     exp = {k: a["out." + k] for k in cfg["keys"]}
-    _compare(name, got, exp, cfg["keys"], TOL, stochastic=cfg["perturb"] > 0)
+    coarse_keys = [k for k in cfg["keys"] if k.endswith("_coarse")]
+    fine_keys = [k for k in cfg["keys"] if k not in coarse_keys]
+    worst = _worst(got, exp, coarse_keys)                      # the coarse pass does not depend on the sampler
+    R = a["rays"].shape[0]
+    same = torch.ones(R, dtype=torch.bool)
+    if z_hip is not None:
+        dz = (z_hip - a["z_fine"]).abs().max(1)[0].double()
+        same = dz <= Z_SAME
+        bound = gu.fixture_conditioning(cfg, a)
+        unexplained = (dz > bound + Z_SAME).nonzero().flatten().tolist()
+        assert not unexplained, (f"{name}: fine depths of rays {unexplained[:8]} differ from the reference's by more than its "
+                                 f"conditioning explains: dz {dz[unexplained[:8]].tolist()} bound {bound[unexplained[:8]].tolist()}")
+    worst.update(_worst(got, exp, fine_keys, same))
+    bad = {k: v for k, v in worst.items() if not v <= TOL}
+    assert not bad, f"{name}: max abs err over {TOL} (rays with the reference's fine depths): {bad} (all: {worst})"
+    n_diff = int((~same).sum())
+    if n_diff:
+        per_ray = [k for k in fine_keys if k not in PER_SAMPLE]
+        loose = _worst(got, exp, per_ray, ~same)
+        print(f"{name}: the fine depths of {n_diff} of {R} rays differ from the reference's (max {dz.max().item():.2e}, all within "
+              f"its conditioning); worst per-ray output difference among them {max(loose.values()):.2e}")
+        bad = {k: v for k, v in loose.items() if not v <= LOOSE}
+        assert not bad, f"{name}: rays with different fine depths differ by more than {LOOSE}: {bad}"
+
+
+@pytest.mark.parametrize("name", [n for n in RENDER if not n.startswith("g4")])
+def test_render_at_reference_depths(name):
+    """Same call with the reference's fine depths injected: 1e-4 on every output of every ray."""
+    import gpu_util
+    cfg, a = gu.load(name)
+    specs, kw = gu.oracle_kwargs(cfg, a)
+    kw["z_fine"] = a["z_fine"]
+    got = gpu_util.hip_render(specs, a["rays"], kw, precision="f16x3")
+    assert list(got.keys()) == cfg["keys"]
+    worst = _worst(got, {k: a["out." + k] for k in cfg["keys"]}, cfg["keys"])
+    bad = {k: v for k, v in worst.items() if not v <= TOL}
+    assert not bad, f"{name}: max abs err over {TOL}: {bad} (all: {worst})"
 
 
 @pytest.mark.parametrize("name", ["g5_cfg2_base", "g6_cfg3_nerfw", "g10_cfg5_xyz15"])

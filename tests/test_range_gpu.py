@@ -1,9 +1,12 @@
 """Numerical range of the fused MLP (VERDICT r1, weak #2d).  The kernels multiply fp16 operands (split hi + lo): an
-activation or weight beyond fp16's range (|x| > 65504) cannot be represented (hi = inf, lo = -inf -> NaN), where the
-fp32 reference simply carries it.  The contract ('Numerical range'):
+activation or weight beyond fp16's range (|x| > 65504) cannot be represented (hi = inf, lo = -inf), where the fp32
+reference simply carries it.  On gfx950 the matrix cores turn inf - inf and inf * 0 into a NEGATIVE quiet NaN
+(profiles/tools/fp16_probe.hip), which the next layer's relu -- one integer max on the bit pattern -- maps to zero: the
+outputs of an out-of-range network are finite and look plausible.  The contract ('Numerical range'):
   * inside the range the 1e-4 parity bar holds, also for activations in the thousands;
-  * outside it the affected rays come out as NaN -- never as finite wrong numbers -- every pass ORs a bit into a
-    device status word, and `check_finite=True` / `nerf_fl_amd.check_status()` raise FloatingPointError.
+  * outside it the kernels REPORT it: every epilogue tracks the largest fp16 operand it forms, the weight packer
+    checks the weights, NFL_STATUS_RANGE is OR-ed into a device status word, and `check_finite=True` /
+    `nerf_fl_amd.check_status()` raise FloatingPointError.
 relu is positively homogeneous, so scaling layer 1 (weight and bias) by K and layer 2's weight by 1/K leaves the
 field's function unchanged while multiplying the layer-1 activations by K: K picks the regime."""
 import pytest
@@ -54,14 +57,11 @@ def test_overflow_is_reported_not_silent():
     K = 2.0 ** 17                      # layer-1 activations ~ 1e5 .. 4e5: beyond fp16
     with pytest.raises(FloatingPointError):
         _run(K, check_finite=True)
-    got, exp = _run(K)                 # without the check: NaN, never a finite wrong number
+    got, exp = _run(K)                 # without the check the call returns (wrong numbers) ...
     assert all(torch.isfinite(v).all() for v in exp.values()), "the fp32 reference carries these magnitudes"
-    bad = ~torch.isfinite(got["rgb_fine"]).all(dim=1)
-    assert bad.any()
-    ok = ~bad & ~torch.isfinite(got["rgb_coarse"]).all(dim=1).logical_not()
-    assert (got["rgb_fine"][ok] - exp["rgb_fine"][ok]).abs().max().item() <= 1e-4 if ok.any() else True
-    with pytest.raises(FloatingPointError):
-        nerf_fl_amd.check_status()
+    assert max((got[k] - exp[k]).abs().max().item() for k in exp) > 1e-4, "this input is meant to break the fp16 path"
+    with pytest.raises(FloatingPointError, match="fp16's range"):
+        nerf_fl_amd.check_status()     # ... and the status word has recorded why
     nerf_fl_amd.check_status()         # cleared by the raise
 
 

@@ -3,14 +3,14 @@
 bins, a single spike, weight only in the two dropped columns, u = 0 / 1 / 1 - 2^-24, per-ray depth ranges,
 jittered coarse depths.  Fixture: tests/golden/g3b_sample_pdf_coarse.npz, produced by the real reference.
 
-What "equal" means here.  Given the same normalising sum the kernel reproduces the reference's CPU arithmetic
-operation for operation (fp64-accumulated cumsum included, see nfl_sample.hip); the one quantity it cannot
-reproduce is torch.sum's fp32 rounding, which depends on the host's vector width.  An ulp in that sum moves
-every cdf entry by at most an ulp, and a draw by  ulp(1) * (bin width) / (bin probability): the test bounds each
-draw by exactly that conditioning (CDF_ULPS ulps of the cdf), i.e. it asks for ulp-level agreement of the CDF,
-and reports how many draws are bit-identical (all draws of every ray whose sum rounds the same way).  sample_pdf
-is also piecewise -- bin choice by searchsorted, `denom < eps -> 1` (rendering.py:33-42) -- so a draw within those
-few ulps of a breakpoint may fall on either side; `_admissible_error` spells the rule out.
+What "equal" means here.  The kernel reproduces the reference's CPU arithmetic operation for operation (ATen's
+fp32 summation order, its fp64-accumulated cumsum, separately rounded fp32 elsewhere; see nfl_sample.hip), so on
+identical inputs every draw must be BIT-IDENTICAL to the fixture -- that is the assertion.  Beside it the test keeps
+a weaker, implementation-independent rule (`_admissible_error`): an ulp in the normalising sum moves every cdf
+entry by at most an ulp and a draw by  ulp(1) * (bin width) / (bin probability), and sample_pdf is piecewise -- bin
+choice by searchsorted, `denom < eps -> 1` (rendering.py:33-42) -- so a draw within a few ulps of a breakpoint may
+fall on either side.  That rule is what end-to-end comparisons can rely on when the coarse weights themselves
+differ in their last bits (tests/golden_util.py: sampling_conditioning).
 """
 import ctypes as C
 
@@ -44,13 +44,14 @@ def _hip_sample(z, w, u, I):
 
 
 def _kernel_model(z, w, u):
-    """The arithmetic nfl_sample.hip performs, restated with numpy (fp64 sum and scan rounded once, everything else
-    fp32 operation by operation).  Used on the CPU to check this file's acceptance rule without a GPU."""
+    """The arithmetic nfl_sample.hip performs, restated with numpy (the sum in ATen's CPU order -- here simply torch.sum
+    --, the scan in fp64 rounded once per entry, everything else fp32 operation by operation).  Used on the CPU to
+    check this file's acceptance rule without a GPU."""
     z, w, u = z.numpy(), w.numpy(), u.numpy()
     R, S = z.shape
     eps = np.float32(EPS)
     ww = (w[:, 1:-1] + eps).astype(np.float32)
-    total = ww.astype(np.float64).sum(1).astype(np.float32)
+    total = torch.from_numpy(ww).sum(1).numpy()          # the kernel follows ATen's CPU summation order exactly
     pdf = (ww / total[:, None]).astype(np.float32)
     cdf = np.concatenate([np.zeros((R, 1), np.float32), np.cumsum(pdf.astype(np.float64), 1).astype(np.float32)], 1)
     mids = (np.float32(0.5) * (z[:, :-1] + z[:, 1:])).astype(np.float32)
@@ -105,7 +106,7 @@ def _admissible_error(z, w, u, smp):
     return best
 
 
-def _check(z, w, u, smp, exp, label):
+def _check(z, w, u, smp, exp, label, min_exact=1.0):
     ratio = _admissible_error(z, w, u, smp)
     exact = float((smp == exp).float().mean())
     print(f"sample_pdf[{label}]: {100 * exact:.2f}% of {smp.numel()} draws bit-identical to the reference, "
@@ -113,7 +114,7 @@ def _check(z, w, u, smp, exp, label):
     assert float(_admissible_error(z, w, u, exp).max()) <= 1.0, "the reference's own output must satisfy the rule"
     bad = (ratio > 1.0).nonzero()
     assert bad.numel() == 0, f"{bad.shape[0]} draws further than {CDF_ULPS} cdf-ulps from the reference, e.g. {bad[:4].tolist()}"
-    assert exact >= 0.85, "draws of rays whose normalising sum rounds the same way must be bit-identical"
+    assert exact >= min_exact, "the kernel follows the reference's CPU arithmetic: the draws must be bit-identical"
 
 
 def _inputs(mode):
