@@ -67,7 +67,12 @@ def test_render_vs_golden(name):
         unexplained = (dz > bound + Z_SAME).nonzero().flatten().tolist()
         assert not unexplained, (f"{name}: fine depths of rays {unexplained[:8]} differ from the reference's by more than its "
                                  f"conditioning explains: dz {dz[unexplained[:8]].tolist()} bound {bound[unexplained[:8]].tolist()}")
-    worst.update(_worst(got, exp, fine_keys, same))
+    # per-ray outputs: rays whose depths agree to Z_SAME.  Per-sample arrays (raw field values at the depths: a trained
+    # transient density moves by 3e-4 for ONE ulp of z, 4.8e-7 at z = 5): rays whose depths are bit-identical; the
+    # injected-depth test below covers them on every ray.
+    worst.update(_worst(got, exp, [k for k in fine_keys if k not in PER_SAMPLE], same))
+    if z_hip is not None:
+        worst.update(_worst(got, exp, [k for k in fine_keys if k in PER_SAMPLE], dz == 0))
     bad = {k: v for k, v in worst.items() if not v <= TOL}
     assert not bad, f"{name}: max abs err over {TOL} (rays with the reference's fine depths): {bad} (all: {worst})"
     n_diff = int((~same).sum())
