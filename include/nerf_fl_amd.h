@@ -103,9 +103,23 @@ int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_param
 
 /* ---- one rendering pass (reference: inference(), rendering.py:83-226) --- */
 
+/* A pinhole camera from which a pass can generate its rays in the prologue instead of reading a ray matrix (reference
+ * datasets/ray_utils.py:5-55, get_ray_directions + get_rays; same arithmetic as nfl_gen_rays): ray r of the pass is
+ * pixel pix0 + r in row-major order of a frame `width` pixels wide; direction [(i - cx) / fx, -(j - cy) / fy, -1] (no
+ * half-pixel) rotated by c2w[:, :3] and normalised, origin c2w[:, 3], bounds near / far. */
+typedef struct nfl_camera {
+    float   c2w[12];            /* 3 x 4 row-major */
+    float   fx, fy, cx, cy;
+    int32_t width, reserved;
+    int64_t pix0;
+    float   near, far;
+} nfl_camera;
+
 typedef struct nfl_pass_args {
     /* geometry */
-    const float* d_rays;        /* (R,8): o(3) d(3) near far   (rendering.py:231-233)  */
+    const float* d_rays;        /* (R,8): o(3) d(3) near far   (rendering.py:231-233); may be NULL when h_cam is set */
+    const nfl_camera* h_cam;    /* HOST pointer or NULL: generate the rays of this pass from the camera (copied at launch;
+                                   inference only: not with d_act_stash)                                             */
     const float* d_view_dir;    /* (R,3) or NULL -> use rays_d (rendering.py:236-238)  */
     int32_t n_rays;             /* R                                                     */
     int32_t n_samples;          /* samples per ray in THIS pass: N_samples (coarse) or N_samples+N_importance (fine) */

@@ -40,9 +40,14 @@ class FieldParams(C.Structure):
     _fields_ = [("weight", C.c_void_p * NFL_NUM_LAYERS), ("bias", C.c_void_p * NFL_NUM_LAYERS)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("c2w", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("width", C.c_int32), ("reserved", C.c_int32), ("pix0", C.c_int64), ("near", C.c_float), ("far", C.c_float)]
+
+
 class PassArgs(C.Structure):
     _fields_ = [
-        ("d_rays", C.c_void_p), ("d_view_dir", C.c_void_p),
+        ("d_rays", C.c_void_p), ("h_cam", C.POINTER(Camera)), ("d_view_dir", C.c_void_p),
         ("n_rays", C.c_int32), ("n_samples", C.c_int32),
         ("d_z", C.c_void_p), ("d_lin", C.c_void_p), ("d_perturb_rand", C.c_void_p),
         ("perturb", C.c_float), ("use_disp", C.c_int32),

@@ -35,32 +35,25 @@ extern "C" int nfl_posenc(const float* d_x, int32_t n, int32_t n_freqs, const fl
 // -> camera direction [(i - cx) / fx, -(j - cy) / fy, -1] (no half-pixel), rotated by c2w[:, :3], normalised;
 // origin = c2w[:, 3].  One thread per ray writes the (8)-float row render_rays takes: [o, d, near, far], so an
 // eval loop needs only (pose, intrinsics) per frame, not a host-built ray tensor.
-struct NflPose {
-    float m[12];         // c2w, 3 x 4 row-major
-};
-__global__ __launch_bounds__(256) void nfl_gen_rays_kernel(const NflPose P, float fx, float fy, float cx, float cy, int W,
-                                                           long long start, int count, float near, float far, float* rays) {
+__global__ __launch_bounds__(256) void nfl_gen_rays_kernel(const nfl_camera cam, int count, float* rays) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= count) return;
-    const long long p = start + idx;
-    const float i = (float)(p % W), j = (float)(p / W);
-    const float dx = (i - cx) / fx, dy = -(j - cy) / fy, dz = -1.f;
-    float d[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) d[r] = dx * P.m[4 * r] + dy * P.m[4 * r + 1] + dz * P.m[4 * r + 2];
-    const float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    float4* o = reinterpret_cast<float4*>(rays + (size_t)idx * 8);
-    o[0] = make_float4(P.m[3], P.m[7], P.m[11], d[0] / n);
-    o[1] = make_float4(d[1] / n, d[2] / n, near, far);
+    f4v r0, r1;
+    nfl_cam_ray(cam, cam.pix0 + idx, r0, r1);          // shared with the render kernel's camera prologue
+    f4v* o = reinterpret_cast<f4v*>(rays + (size_t)idx * 8);
+    o[0] = r0;
+    o[1] = r1;
 }
 
 extern "C" int nfl_gen_rays(const float* h_c2w, float fx, float fy, float cx, float cy, int32_t width, int64_t start,
                             int32_t count, float near, float far, float* d_rays, void* stream) {
     if (!h_c2w || !d_rays || width < 1 || start < 0 || count < 0 || fx == 0.f || fy == 0.f) return NFL_EINVAL;
     if (count == 0) return NFL_OK;
-    NflPose P;
-    for (int k = 0; k < 12; ++k) P.m[k] = h_c2w[k];
-    hipLaunchKernelGGL(nfl_gen_rays_kernel, dim3((count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), P, fx,
-                       fy, cx, cy, width, (long long)start, count, near, far, d_rays);
+    nfl_camera cam;
+    for (int k = 0; k < 12; ++k) cam.c2w[k] = h_c2w[k];
+    cam.fx = fx; cam.fy = fy; cam.cx = cx; cam.cy = cy;
+    cam.width = width; cam.reserved = 0; cam.pix0 = start; cam.near = near; cam.far = far;
+    hipLaunchKernelGGL(nfl_gen_rays_kernel, dim3((count + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), cam,
+                       count, d_rays);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

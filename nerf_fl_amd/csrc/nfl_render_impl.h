@@ -58,6 +58,19 @@ NFL_DEV void nfl_static_for(F&& f) {
 #define NFL_NST 20            // floats in a segment / ray compositing record
 #define NFL_REC 32            // record stride (floats)
 
+// ray of pixel p of a frame (reference datasets/ray_utils.py:5-55); the ONE implementation behind nfl_gen_rays and the
+// render kernel's camera prologue, so that both produce the same bits
+NFL_DEV void nfl_cam_ray(const nfl_camera& c, long long p, f4v& r0, f4v& r1) {
+    const float i = (float)(p % c.width), j = (float)(p / c.width);
+    const float dx = (i - c.cx) / c.fx, dy = -(j - c.cy) / c.fy, dz = -1.f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = dx * c.c2w[4 * r] + dy * c.c2w[4 * r + 1] + dz * c.c2w[4 * r + 2];
+    const float n = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    r0 = f4v{c.c2w[3], c.c2w[7], c.c2w[11], d[0] / n};
+    r1 = f4v{d[1] / n, d[2] / n, c.near, c.far};
+}
+
 struct RenderArgs {
     const NflPlan* plan;      // device copy of the plan
     const char* packed;       // fragment stream, then bias table at plan->bias_off
@@ -71,6 +84,8 @@ struct RenderArgs {
     int rays_per_wg;
     float beta_min;
     int n_points, emb_stride;   // NFL_MODE_EMBED: rows / row stride (floats) of a.d_embedded
+    int gen_rays;               // rays come from `cam` (nfl_pass_args::h_cam), not from a.d_rays
+    nfl_camera cam;
 };
 
 // ---------------------------------------------------------------------------------
@@ -723,9 +738,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 }
                 continue;
             }
-            const float* rp = a.d_rays + (size_t)ray * 8;
-            const f4v r0 = *reinterpret_cast<const f4v*>(rp);
-            const f4v r1 = *reinterpret_cast<const f4v*>(rp + 4);
+            f4v r0, r1;
+            if (A.gen_rays) {
+                nfl_cam_ray(A.cam, A.cam.pix0 + ray, r0, r1);
+            } else {
+                const float* rp = a.d_rays + (size_t)ray * 8;
+                r0 = *reinterpret_cast<const f4v*>(rp);
+                r1 = *reinterpret_cast<const f4v*>(rp + 4);
+            }
             const float near = r1[2], far = r1[3];
             const float z = nfl_z_at(a, ray, near, far, ii);
             const float zn = ii + 1 < N ? nfl_z_at(a, ray, near, far, ii + 1) : z;
@@ -809,14 +829,21 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         }
                         continue;
                     }
-                    const float* dp = a.d_view_dir ? a.d_view_dir + (size_t)s_ray[cb] * 3
-                                                   : a.d_rays + (size_t)s_ray[cb] * 8 + 3;
                     float raw[3], th[3], tl[3];
+                    if (A.gen_rays && !a.d_view_dir) {
+                        f4v g0, g1;
+                        nfl_cam_ray(A.cam, A.cam.pix0 + s_ray[cb], g0, g1);
+                        raw[0] = g0[3];
+                        raw[1] = g1[0];
+                        raw[2] = g1[1];
+                    } else {
+                        const float* dp = a.d_view_dir ? a.d_view_dir + (size_t)s_ray[cb] * 3
+                                                       : a.d_rays + (size_t)s_ray[cb] * 8 + 3;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        raw[k] = dp[k];
-                        nfl_turns(raw[k], th[k], tl[k]);
+                        for (int k = 0; k < 3; ++k) raw[k] = dp[k];
                     }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) nfl_turns(raw[k], th[k], tl[k]);
                     char* sd = STASH ? st[cb] + nfl_act_d(NKP) * 1024 : nullptr;
                     nfl_pe_kstep<4, NP>(0, h, raw, th, tl, pw_lds + 16, D[0][cb], sd);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1081,6 +1108,12 @@ static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void
     A.use_t = (hp->has_t && args->d_t_emb != nullptr && !args->sigma_only) ? 1 : 0;
     A.n_points = 0;
     A.emb_stride = 0;
+    A.gen_rays = 0;
+    if (args->h_cam != nullptr && MODE != NFL_MODE_EMBED) {
+        A.gen_rays = 1;
+        A.cam = *args->h_cam;
+        A.a.h_cam = nullptr;              // a host pointer has no business on the device
+    }
     if (MODE == NFL_MODE_EMBED) {      // n_rays = segments of 32 points; d_t_emb != NULL only flags "transient head on"
         A.n_points = args->n_points;
         A.emb_stride = args->embedded_stride;

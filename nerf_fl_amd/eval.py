@@ -12,9 +12,10 @@ per-key results.  Differences that matter on MI355X:
 """
 import torch
 
-from .rendering import render_rays
+from . import parallel
+from .rendering import CameraRays, render_rays
 
-__all__ = ["batched_inference", "GraphedChunk"]
+__all__ = ["batched_inference", "GraphedChunk", "frame_rays", "to_uint8", "dolly_path", "render_frame", "render_video"]
 
 
 class GraphedChunk:
@@ -47,11 +48,15 @@ class GraphedChunk:
 
     def __call__(self, rays, ts, **latents):
         n = rays.shape[0]
+        if isinstance(rays, CameraRays):      # a captured launch freezes by-value arguments (the camera): materialise
+            rays = frame_rays_of(rays)        # the rows into the static buffer with nfl_gen_rays instead
         self.rays[:n].copy_(rays)
-        self.ts[:n].copy_(ts)
+        if ts is not None:
+            self.ts[:n].copy_(ts)
         if n < self.chunk:                                   # ragged tail: repeat the last ray
             self.rays[n:].copy_(rays[-1:].expand(self.chunk - n, -1))
-            self.ts[n:].copy_(ts[-1:].expand(self.chunk - n))
+            if ts is not None:
+                self.ts[n:].copy_(ts[-1:].expand(self.chunk - n))
         for k, buf in self.kw_static.items():
             if k in latents:
                 buf.copy_(latents[k].expand(self.chunk, -1))
@@ -75,7 +80,8 @@ def batched_inference(models, embeddings, rays, ts, N_samples, N_importance, use
                                       white_back, **kwargs)
         runner = cache[key]
     for i in range(0, B, chunk):
-        r, t = rays[i:i + chunk], ts[i:i + chunk]
+        r = rays.slice(i, i + chunk) if isinstance(rays, CameraRays) else rays[i:i + chunk]
+        t = ts[i:i + chunk] if ts is not None else None         # reference eval.py:94
         if runner is not None:
             out = {k: v.clone() for k, v in runner(r, t).items()}
         else:
@@ -108,3 +114,63 @@ def frame_rays(c2w, K, H, W, near, far, device, start=0, count=None):
                                            int(start), count, float(near), float(far), C.c_void_p(rays.data_ptr()),
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "nfl_gen_rays")
     return rays
+
+
+def frame_rays_of(cam_rays):
+    """The (count, 8) matrix a CameraRays stands for."""
+    c = cam_rays.cam
+    c2w = torch.tensor(list(c.c2w), dtype=torch.float32).reshape(3, 4)
+    K = torch.tensor([[c.fx, 0.0, c.cx], [0.0, c.fy, c.cy], [0.0, 0.0, 1.0]])
+    return frame_rays(c2w, K, cam_rays.H, cam_rays.W, c.near, c.far, cam_rays.device, cam_rays.start, cam_rays.count)
+
+
+def to_uint8(rgb):
+    """clip to [0, 1], x 255, truncate -- the reference's image conversion (eval.py:201-203: np.clip(...), (img * 255)
+    .astype(np.uint8)) -- on the device, so a frame leaves the GPU as 3 bytes per pixel instead of 12."""
+    return (rgb.clamp(0.0, 1.0) * 255.0).to(torch.uint8)
+
+
+def dolly_path(c2w0, n_frames=120, dx=0.03, dy=-0.1, dz=0.5):
+    """Camera path of the reference's novel-view video (eval.py:169-183): `n_frames` copies of a training pose whose
+    translation moves linearly by (dx, dy, dz) -- the reference hard-codes exactly this for brandenburg_gate (pose of
+    image 1123, 30 * 4 frames, 0.03 / -0.1 / 0.5) and raises NotImplementedError for every other scene; here it is the
+    path of any scene (configs[4], trevi_fountain: choose the start pose and the deltas).  Returns (n_frames, 3, 4)."""
+    c2w0 = torch.as_tensor(c2w0, dtype=torch.float32)[:3, :4]
+    poses = c2w0[None].repeat(n_frames, 1, 1)
+    for axis, d in enumerate((dx, dy, dz)):
+        poses[:, axis, 3] += torch.linspace(0, d, n_frames)
+    return poses
+
+
+def fov60_intrinsics(W, H):
+    """The reference's test camera (eval.py:164-168): fov 60 degrees, principal point at the image centre."""
+    import math
+    f = W / 2 / math.tan(math.pi / 6)
+    return torch.tensor([[f, 0.0, W / 2], [0.0, f, H / 2], [0.0, 0.0, 1.0]])
+
+
+@torch.no_grad()
+def render_frame(models, embeddings, c2w, K, H, W, near, far, N_samples, N_importance, ts=None, use_disp=False,
+                 chunk=1024 * 128, white_back=False, device="cuda:0", use_graph=False, _graph_cache=None, **kwargs):
+    """One H x W frame from (pose, intrinsics): the rays are generated in the render kernel's prologue (CameraRays), the
+    image is converted on the device.  Returns (uint8 (H, W, 3), dict of the float outputs).  `ts`: image id for the
+    latent tables -- an int, a (H*W,) tensor, or None when `a_embedded` is given / the model has no latent inputs."""
+    cam = CameraRays(c2w, K, H, W, near, far, device)
+    if isinstance(ts, int):
+        ts = torch.full((H * W,), ts, dtype=torch.long, device=cam.device)
+    res = batched_inference(models, embeddings, cam, ts, N_samples, N_importance, use_disp, chunk, white_back,
+                            use_graph=use_graph, _graph_cache=_graph_cache, **kwargs)
+    return to_uint8(res["rgb_fine" if "rgb_fine" in res else "rgb_coarse"]).view(H, W, 3), res
+
+
+@torch.no_grad()
+def render_video(models, embeddings, poses, K, H, W, near, far, N_samples, N_importance, rank=0, world=1, **kwargs):
+    """Frames of a camera path, sharded over ranks with no collective: rank r renders the contiguous block
+    parallel.shard_bounds(n_frames, r, world) and returns (first frame index, uint8 (n_local, H, W, 3)).  (The
+    reference renders every frame on one GPU, eval.py:186-194.)"""
+    lo, hi = parallel.shard_bounds(len(poses), rank, world)
+    cache = kwargs.pop("_graph_cache", {})
+    frames = [render_frame(models, embeddings, poses[i], K, H, W, near, far, N_samples, N_importance, _graph_cache=cache,
+                           **kwargs)[0] for i in range(lo, hi)]
+    dev = kwargs.get("device", "cuda:0")
+    return lo, (torch.stack(frames) if frames else torch.empty(0, H, W, 3, dtype=torch.uint8, device=dev))

@@ -33,7 +33,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["render_rays", "set_precision", "get_precision", "check_status"]
+__all__ = ["render_rays", "set_precision", "get_precision", "check_status", "CameraRays"]
 
 _PREC = {"f16x3": _lib.NFL_PREC_F16X3, "f16": _lib.NFL_PREC_F16}
 _precision = os.environ.get("NERF_FL_AMD_PREC", "f16x3")
@@ -53,6 +53,41 @@ def get_precision():
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class CameraRays:
+    """Stand-in for a `rays` matrix whose rows are the pixels [start, start + count) of an H x W frame seen through a
+    pinhole camera (pose `c2w` (3|4, 4), intrinsics `K` (3, 3), bounds near / far): pass it to render_rays instead of the
+    (N_rays, 8) tensor and the rays are generated inside the render kernel's prologue (reference
+    datasets/ray_utils.py:5-55 + the near/far columns of the datasets) -- an eval loop then moves 12 pose floats per
+    frame instead of 32 B per ray.  Inference only.  `nerf_fl_amd.eval.frame_rays` materialises the same rows."""
+
+    def __init__(self, c2w, K, H, W, near, far, device, start=0, count=None):
+        count = H * W - start if count is None else int(count)
+        if start < 0 or count < 0 or start + count > H * W:
+            raise ValueError("pixel range outside the frame")
+        c2w = torch.as_tensor(c2w, dtype=torch.float32).cpu()[:3, :4].contiguous()
+        K = torch.as_tensor(K, dtype=torch.float32).cpu()
+        self.device = torch.device(device)
+        self.H, self.W, self.start, self.count = int(H), int(W), int(start), count
+        self.shape = (count, 8)
+        self.requires_grad = False
+        self.cam = _lib.Camera()
+        for k, v in enumerate(c2w.reshape(-1).tolist()):
+            self.cam.c2w[k] = v
+        self.cam.fx, self.cam.fy, self.cam.cx, self.cam.cy = float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2])
+        self.cam.width, self.cam.reserved, self.cam.pix0 = int(W), 0, int(start)
+        self.cam.near, self.cam.far = float(near), float(far)
+
+    def slice(self, lo, hi):
+        """Rows [lo, hi) as another CameraRays (what `rays[lo:hi]` is for a tensor)."""
+        out = CameraRays.__new__(CameraRays)
+        out.__dict__.update(self.__dict__)
+        hi = min(hi, self.count)
+        out.start, out.count, out.shape = self.start + lo, hi - lo, (hi - lo, 8)
+        out.cam = _lib.Camera.from_buffer_copy(self.cam)
+        out.cam.pix0 = self.start + lo
+        return out
 
 
 _status_words = {}
@@ -291,7 +326,11 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
         nb = _lib.lib().nfl_act_stash_bytes(C.byref(field.desc), R, n_samples)
         out["act_stash"] = torch.empty(nb, dtype=torch.uint8, device=dev)
     a = _lib.PassArgs()
-    a.d_rays, a.d_view_dir = _ptr(rays), _ptr(view_dir)
+    if isinstance(rays, CameraRays):
+        a.d_rays, a.h_cam = C.c_void_p(0), C.pointer(rays.cam)
+    else:
+        a.d_rays = _ptr(rays)
+    a.d_view_dir = _ptr(view_dir)
     a.n_rays, a.n_samples = R, n_samples
     a.d_z, a.d_lin, a.d_perturb_rand = _ptr(z), _ptr(lin), _ptr(perturb_rand)
     a.perturb, a.use_disp = float(perturb), int(bool(use_disp))
@@ -485,11 +524,14 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
     """See the reference docstring (models/rendering.py:63-81); `chunk` is accepted and
     ignored -- the fused kernel never materialises per-sample tensors, so there is
     nothing to chunk."""
-    rays_in = rays[:, :8] if rays.shape[1] > 8 else rays
-    rays_grad = bool(isinstance(rays_in, torch.Tensor) and rays_in.requires_grad and torch.is_grad_enabled())
-    rays = _f32c(rays_in, "rays")
-    if rays.dim() != 2 or rays.shape[1] != 8:
-        raise ValueError("rays must be (N_rays, 8): origin, direction, near, far")
+    if isinstance(rays, CameraRays):          # rays generated in the kernel prologue (build-defined; inference only)
+        rays_in, rays_grad = rays, False
+    else:
+        rays_in = rays[:, :8] if rays.shape[1] > 8 else rays
+        rays_grad = bool(isinstance(rays_in, torch.Tensor) and rays_in.requires_grad and torch.is_grad_enabled())
+        rays = _f32c(rays_in, "rays")
+        if rays.dim() != 2 or rays.shape[1] != 8:
+            raise ValueError("rays must be (N_rays, 8): origin, direction, near, far")
     R, dev = rays.shape[0], rays.device
     with torch.cuda.device(dev):
         n_xyz, n_dir = _n_freqs(embeddings["xyz"]), _n_freqs(embeddings["dir"])
@@ -558,6 +600,8 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
             rays_grad or any(p.requires_grad for p in params)
             or any(t is not None and t.requires_grad for t in (a_emb, t_emb)))
         if needs_grad:
+            if isinstance(rays, CameraRays):
+                raise RuntimeError("CameraRays is an inference input; call render_rays under torch.no_grad()")
             if test_time:
                 raise RuntimeError("test_time=True is an inference mode; call it under torch.no_grad()")
             if _precision != "f16x3":

@@ -1,0 +1,58 @@
+"""Inputs of the end-to-end PSNR parity runs (tests/golden/make_psnr_ref.py trains the real reference on them here in
+the build container; tests/test_psnr_parity_gpu.py trains the HIP renderer on the same numbers on the GPU box).  Every
+array is a pure function of (seed, step) through numpy PCG64, so both sides see identical batches and random draws.
+
+The scene: a shaded, striped unit sphere in front of a white background (Blender-like rays: near 2, far 6), seen in
+`n_vocab` "images" that differ by a colour tint (appearance) and, every third one, by a grey occluder across part of
+the view (transient) -- what the NeRF-W heads exist for."""
+import numpy as np
+import torch
+
+from oracle import nerfw_oracle as orc
+
+CONFIGS = {
+    # configs[1]-like: base NeRF coarse + fine at the metric's sampling (64 + 64)
+    "base": dict(fine="base", S=64, I=64, R=256, steps=500, lr=5e-4, seed=301, n_vocab=12, n_val=512),
+    # configs[2]-like: NeRF-W (appearance + transient heads, beta, latent tables) at 64 + 64
+    "nerfw": dict(fine="at", S=64, I=64, R=256, steps=500, lr=5e-4, seed=401, n_vocab=12, n_val=512),
+}
+
+
+def colors(rays, ts, cfg, clean=False):
+    o, d = rays[:, :3].numpy().astype(np.float64), rays[:, 3:6].numpy().astype(np.float64)
+    b = (o * d).sum(1)
+    disc = b * b - ((o * o).sum(1) - 1.0)
+    hit = disc > 0
+    t = -b - np.sqrt(np.where(hit, disc, 0.0))
+    n = o + d * t[:, None]
+    stripes = 0.5 + 0.5 * np.sign(np.sin(7.0 * n[:, 0]) * np.sin(7.0 * n[:, 1]))
+    col = np.clip(0.5 + 0.5 * n, 0, 1) * (0.55 + 0.45 * stripes[:, None])
+    if cfg["fine"] == "at" and not clean:
+        tint = 0.8 + 0.2 * np.random.default_rng(cfg["seed"] + 9).uniform(-1, 1, size=(cfg["n_vocab"], 3))
+        col = col * tint[ts.numpy()]
+    col = np.where(hit[:, None], col, 1.0)
+    if cfg["fine"] == "at" and not clean:
+        occ = (ts.numpy() % 3 == 0) & (d[:, 0] > 0.05)
+        col = np.where(occ[:, None], 0.35, col)
+    return torch.from_numpy(np.clip(col, 0, 1).astype(np.float32))
+
+
+def batch(cfg, step):
+    rays = orc.make_rays(cfg["R"], cfg["seed"] * 100000 + step)
+    ts = torch.from_numpy(np.random.default_rng(cfg["seed"] * 100000 + 50000 + step).integers(0, cfg["n_vocab"], size=cfg["R"]).astype(np.int64))
+    return rays, ts, colors(rays, ts, cfg)
+
+
+def val_batch(cfg):
+    """Validation: image id 1 (tinted, never occluded) so the target is the static scene under that image's appearance."""
+    rays = orc.make_rays(cfg["n_val"], cfg["seed"] * 100000 + 99999)
+    ts = torch.ones(cfg["n_val"], dtype=torch.int64)
+    return rays, ts, colors(rays, ts, cfg)
+
+
+def draws(cfg, step):
+    rng = np.random.default_rng(cfg["seed"] * 100000 + 70000 + step)
+    R, S, I = cfg["R"], cfg["S"], cfg["I"]
+    f = lambda a: torch.from_numpy(a.astype(np.float32))
+    return dict(perturb_rand=f(rng.uniform(0, 1, size=(R, S))), noise_coarse=f(rng.standard_normal((R, S))),
+                u=f(rng.uniform(0, 1, size=(R, I))), noise_fine=f(rng.standard_normal((R, S + I))))

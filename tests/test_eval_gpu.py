@@ -58,3 +58,77 @@ def test_frame_rays_match_ray_utils_restatement():
     part = frame_rays(c2w, K, H, W, 2.0, 6.0, "cuda:0", start=101, count=333).cpu()
     assert torch.equal(part, got[101:434])
     assert frame_rays(c2w, K, H, W, 2.0, 6.0, "cuda:0", start=5, count=0).shape == (0, 8)
+
+
+def _nerfw_models(dev, n_vocab=50):
+    import gpu_util
+    from nerf_fl_amd import PosEmbedding
+    spec_c = orc.FieldSpec("coarse")
+    spec_f = orc.FieldSpec("fine", encode_appearance=True, encode_transient=True, beta_min=0.1)
+    models = {"coarse": gpu_util.module_from(spec_c, orc.make_field_params(spec_c, 3, "sharp")),
+              "fine": gpu_util.module_from(spec_f, orc.make_field_params(spec_f, 4, "sharp"))}
+    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4),
+           "a": torch.nn.Embedding(n_vocab, 48).to(dev), "t": torch.nn.Embedding(n_vocab, 16).to(dev)}
+    return models, emb
+
+
+def test_camera_prologue_equals_materialised_rays():
+    """Rays generated inside the render kernel's prologue (CameraRays: only pose + intrinsics cross the boundary) give
+    bit-identical results to rendering the ray matrix nfl_gen_rays writes for the same pixels."""
+    import gpu_util
+    from nerf_fl_amd import CameraRays, render_rays
+    from nerf_fl_amd.eval import frame_rays, fov60_intrinsics
+    from nerf_fl_amd.poses import make_c2w
+    dev = gpu_util.DEV
+    models, emb = _nerfw_models(dev)
+    H, W = 23, 31
+    K = fov60_intrinsics(W, H)
+    c2w = make_c2w(torch.tensor([0.1, -0.2, 0.05]), torch.tensor([0.1, -0.2, 3.9]))[:3]
+    cam = CameraRays(c2w, K, H, W, 2.0, 6.0, dev, start=17, count=600)
+    rays = frame_rays(c2w, K, H, W, 2.0, 6.0, dev, start=17, count=600)
+    ts = torch.randint(0, 50, (600,), device=dev)
+    with torch.no_grad():
+        a = render_rays(models, emb, cam, ts, 64, False, 0, 0, 64, 32768, True, True)
+        b = render_rays(models, emb, rays, ts, 64, False, 0, 0, 64, 32768, True, True)
+        c = render_rays(models, emb, cam.slice(100, 228), ts[100:228], 64, False, 0, 0, 64, 32768, True, True)
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert torch.equal(c[k], b[k][100:228]), k
+    with pytest.raises(RuntimeError):          # inference input only
+        render_rays(models, emb, cam, ts, 64, False, 0, 0, 64, 32768, True, False)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_render_frame_and_sharded_video(use_graph):
+    """render_frame (camera prologue, device-side clip -> uint8, ts as an int / None with a_embedded) and render_video
+    (frames sharded over ranks without a collective) against the plain path (reference eval.py:162-210)."""
+    import gpu_util
+    from nerf_fl_amd.eval import batched_inference, dolly_path, frame_rays, render_frame, render_video, fov60_intrinsics, to_uint8
+    from nerf_fl_amd.poses import make_c2w
+    dev = gpu_util.DEV
+    models, emb = _nerfw_models(dev)
+    H, W, S, I = 20, 24, 32, 32
+    K = fov60_intrinsics(W, H)
+    poses = dolly_path(make_c2w(torch.tensor([0.0, 0.1, 0.0]), torch.tensor([0.0, 0.0, 4.0]))[:3], n_frames=5)
+    kw = dict(chunk=128, white_back=True, device=dev, output_transient=False)
+    img, res = render_frame(models, emb, poses[2], K, H, W, 2.0, 6.0, S, I, ts=7, use_graph=use_graph, **kw)
+    rays = frame_rays(poses[2], K, H, W, 2.0, 6.0, dev)
+    exp = batched_inference(models, emb, rays, torch.full((H * W,), 7, dtype=torch.long, device=dev), S, I, chunk=128,
+                            white_back=True, output_transient=False)
+    assert img.dtype == torch.uint8 and tuple(img.shape) == (H, W, 3)
+    assert torch.equal(res["rgb_fine"], exp["rgb_fine"])
+    assert torch.equal(img.view(-1, 3), (exp["rgb_fine"].clamp(0, 1) * 255).to(torch.uint8))
+    assert torch.equal(to_uint8(torch.tensor([[-0.5, 0.5, 1.7]])), torch.tensor([[0, 127, 255]], dtype=torch.uint8))
+    # ts=None (reference eval.py:94) with the appearance code given explicitly, as the notebooks do
+    a_emb = emb["a"](torch.tensor([7], device=dev))
+    img2, _ = render_frame(models, emb, poses[2], K, H, W, 2.0, 6.0, S, I, ts=None, a_embedded=a_emb.expand(H * W, -1)
+                           if not use_graph else a_emb, use_graph=use_graph, **kw)
+    assert torch.equal(img2, img)
+    # two ranks' shards = the whole video
+    full_lo, full = render_video(models, emb, poses, K, H, W, 2.0, 6.0, S, I, ts=7, **kw)
+    lo0, part0 = render_video(models, emb, poses, K, H, W, 2.0, 6.0, S, I, rank=0, world=2, ts=7, **kw)
+    lo1, part1 = render_video(models, emb, poses, K, H, W, 2.0, 6.0, S, I, rank=1, world=2, ts=7, **kw)
+    assert (full_lo, lo0, lo1) == (0, 0, 3) and part0.shape[0] == 3 and part1.shape[0] == 2
+    assert torch.equal(torch.cat([part0, part1]), full)
+    assert torch.equal(full[2], img)

@@ -56,3 +56,25 @@ def test_rays_and_learnable_pose_gradients():
     assert torch.allclose(rays_o, init[cam][:, :3, 3])
     (rays_o.sum() + (rays_d * torch.arange(3.0)).sum()).backward()             # gradients reach (r, t) of the used cameras
     assert pose.t.grad[0].abs().sum() > 0 and pose.r.grad[2].abs().sum() > 0
+
+
+def test_dolly_path_restates_the_reference_video_path():
+    """nerf_fl_amd.eval.dolly_path against the literal loop of the reference (eval.py:171-183), and the test intrinsics
+    (eval.py:164-168)."""
+    import math
+
+    import numpy as np
+    from nerf_fl_amd.eval import dolly_path, fov60_intrinsics
+    pose = torch.tensor([[1.0, 0.0, 0.0, 0.2], [0.0, 1.0, 0.0, -0.3], [0.0, 0.0, 1.0, 1.5]])
+    n = 120
+    dx, dy, dz = np.linspace(0, 0.03, n), np.linspace(0, -0.1, n), np.linspace(0, 0.5, n)
+    ref = np.tile(pose.numpy(), (n, 1, 1))
+    for i in range(n):
+        ref[i, 0, 3] += dx[i]
+        ref[i, 1, 3] += dy[i]
+        ref[i, 2, 3] += dz[i]
+    got = dolly_path(pose, n)
+    assert got.shape == (n, 3, 4)
+    assert np.abs(got.numpy() - ref).max() <= 1e-6
+    K = fov60_intrinsics(400, 300)
+    assert abs(K[0, 0].item() - 400 / 2 / math.tan(math.pi / 6)) < 1e-3 and K[0, 2] == 200 and K[1, 2] == 150
