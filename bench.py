@@ -54,7 +54,11 @@ def parse_args(argv=None):
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU and step")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f16"])
     ap.add_argument("--graph", action="store_true", help="train mode: replay the step from one captured HIP graph")
+    ap.add_argument("--unfused-loss", action="store_true", help="NerfWLoss as a module on the result dict (two more launches)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the warm-up and the timed steps (no render-only companion, roofline launches or CPU baseline): "
+                         "the command the PMC passes of profiles/collect.sh count bytes over")
     ap.add_argument("--dry", action="store_true")
     return ap.parse_args(argv)
 
@@ -240,15 +244,20 @@ def run_rank(args):
 
     def train_step():
         opt.zero_grad(set_to_none=True)
-        res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False)
-        loss = sum(loss_fn(res, target).values())      # c_l + f_l (+ b_l + s_l), forward and backward one launch each
+        if args.unfused_loss:
+            res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False)
+            loss = sum(loss_fn(res, target).values())  # c_l + f_l (+ b_l + s_l), forward and backward one launch each
+        else:       # NerfWLoss and its backward seeds in the render kernels' per-ray epilogue (losses.py:35-50)
+            loss = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False,
+                               loss_target=target)["_nerfw_loss"]
         loss.backward()
         if dist is not None:
             parallel.all_reduce_gradients(params)
         opt.step()
 
     if args.mode == "train" and args.graph:
-        graphed = GraphedTrainStep(models, emb, params, opt, loss_fn, rays, ts, target, N_SAMPLES, N_IMPORTANCE,
+        graphed = GraphedTrainStep(models, emb, params, opt, loss_fn if args.unfused_loss else None, rays, ts, target,
+                                   N_SAMPLES, N_IMPORTANCE,
                                    white_back=white_back, all_reduce=dist is not None)
         step = graphed.replay
     else:
@@ -307,7 +316,7 @@ def run_rank(args):
                    "mlp_evals_per_ray": N_SAMPLES + F, "hip_graph": bool(args.graph)},
     }
 
-    if args.mode == "train":
+    if args.mode == "train" and not args.no_extras:
         # forward-only throughput of the same batch, reported beside the train-step value
         for _ in range(3):
             render_step()
@@ -319,8 +328,9 @@ def run_rank(args):
         out["render_only_value"] = R * F * n_ranks * 20 / (time.perf_counter() - t0)
 
     if rank == 0:
-        out.update(roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back))
-        if n_ranks == 1 and not args.no_cpu_baseline:
+        if not args.no_extras:
+            out.update(roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back))
+        if n_ranks == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(args.mode)
         print(json.dumps(out))
     if dist is not None:

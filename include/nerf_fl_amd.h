@@ -163,6 +163,18 @@ typedef struct nfl_pass_args {
        computed by the caller exactly as barf_weight(freq, epoch) does; NULL = plain PosEmbedding     */
     const float* d_pe_w_xyz;    /* (n_emb_xyz) or NULL                                                   */
     const float* d_pe_w_dir;    /* (n_emb_dir) or NULL                                                   */
+    /* NerfWLoss fused into the per-ray epilogue of a TRAINING pass (reference losses.py:35-50): with
+       d_loss_target set, every completed ray adds its share of the loss terms to d_losses[4] = {c_l, f_l, b_l, s_l}
+       (float atomics, one flush per workgroup; the caller zeroes the array once per step) -- loss_slot 0: this is the
+       coarse pass (c_l); 1: the fine pass (f_l, and with the transient head b_l and s_l) -- and writes the backward
+       seeds d loss / d rgb (and d loss / d beta) of the ray, which nfl_composite_backward takes as g_rgb / g_beta.
+       The caller then needs none of the per-sample outputs (weights, transient_sigmas) for the loss. */
+    const float* d_loss_target; /* (R,3) target colours, or NULL = no fused loss                                   */
+    float*  d_losses;           /* (4)                                                                              */
+    float*  d_seed_rgb;         /* out (R,3)                                                                        */
+    float*  d_seed_beta;        /* out (R); fine pass with the transient head only                                  */
+    float   loss_coef, lambda_u;/* losses.py:36: coef = 1, lambda_u = 0.01                                          */
+    int32_t loss_slot, reserved2;
     /* optional status word (device, int32, never cleared by the library): NFL_STATUS_* bits are OR-ed in.  The MLP
        multiplies fp16 operands: an activation or a weight beyond fp16's range (|x| > 65504), which the fp32 reference
        would carry, cannot be represented here (hi = inf, lo = -inf; the matrix cores then produce NaNs that the next
@@ -234,6 +246,9 @@ typedef struct nfl_compbwd_args {
     const float* g_beta;            /* (R)    */
     const float* g_rgb_static;      /* (R,3)  _rgb_fine_static                             */
     const float* g_rgb_transient;   /* (R,3)  _rgb_fine_transient                          */
+    float g_tsig_const;             /* added to every element of g_transient_sigmas (s_l's constant gradient coef lambda_u / (R N): no (R,N) array needed) */
+    int32_t reserved3;
+    const float* d_go;              /* device scalar multiplying every gradient above (the upstream gradient of a fused loss) or NULL = 1 */
     float* d_head_grads;            /* out (R*N,9): d/d pre-activation [rgb,sigma,rgb_t,sigma_t,beta] */
     float* d_gmax;                  /* out (NFL_GMAX_SLOTS = 1024 floats): partial maxima of |head gradient| of this pass (zeroed by the call; the consumers take the max) */
 } nfl_compbwd_args;

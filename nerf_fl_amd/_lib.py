@@ -62,7 +62,10 @@ class PassArgs(C.Structure):
         ("d_rgb_static_only", C.c_void_p), ("d_depth_static_only", C.c_void_p),
         ("d_rgb_transient_only", C.c_void_p), ("d_depth_transient_only", C.c_void_p),
         ("d_field_raw", C.c_void_p), ("d_act_stash", C.c_void_p),
-        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p), ("d_status", C.c_void_p),
+        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p),
+        ("d_loss_target", C.c_void_p), ("d_losses", C.c_void_p), ("d_seed_rgb", C.c_void_p), ("d_seed_beta", C.c_void_p),
+        ("loss_coef", C.c_float), ("lambda_u", C.c_float), ("loss_slot", C.c_int32), ("reserved2", C.c_int32),
+        ("d_status", C.c_void_p),
         ("d_embedded", C.c_void_p), ("n_points", C.c_int32), ("embedded_stride", C.c_int32),
     ]
 
@@ -74,7 +77,8 @@ class CompBwdArgs(C.Structure):
         ("reserved", C.c_int32),
         ("g_weights", C.c_void_p), ("g_opacity", C.c_void_p), ("g_rgb", C.c_void_p), ("g_depth", C.c_void_p),
         ("g_transient_sigmas", C.c_void_p), ("g_beta", C.c_void_p), ("g_rgb_static", C.c_void_p),
-        ("g_rgb_transient", C.c_void_p), ("d_head_grads", C.c_void_p), ("d_gmax", C.c_void_p),
+        ("g_rgb_transient", C.c_void_p), ("g_tsig_const", C.c_float), ("reserved3", C.c_int32), ("d_go", C.c_void_p),
+        ("d_head_grads", C.c_void_p), ("d_gmax", C.c_void_p),
     ]
 
 

@@ -69,6 +69,8 @@ int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed
     if (a->perturb > 0.f && !a->d_z && !a->d_perturb_rand) return NFL_EINVAL;
     if (!a->sigma_only && hp->has_a && !a->d_a_emb) return NFL_EINVAL;
     if (hp->is_bwd) return NFL_EINVAL;
+    if (a->d_loss_target && (!a->d_losses || !a->d_seed_rgb || a->loss_slot < 0 || a->loss_slot > 1 || a->sigma_only ||
+                             a->test_extras)) return NFL_EINVAL;
     if (a->n_rays == 0) return NFL_OK;
     if (hp->prec == NFL_PREC_F16X3) return nfl_launch_render_x3(hp, d_plan, d_packed, a, stream);
     return nfl_launch_render_x1(hp, d_plan, d_packed, a, stream);

@@ -53,8 +53,10 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
     const float ns = a.noise_std;
 
     // per-ray output gradients (uniform)
-    auto ld = [&](const float* p, int k) { return p ? p[k] : 0.f; };
+    const float go = a.d_go ? *a.d_go : 1.f;          // upstream gradient of a fused loss (header: d_go)
+    auto ld = [&](const float* p, int k) { return p ? go * p[k] : 0.f; };
     const float gW = ld(a.g_opacity, ray), gD = ld(a.g_depth, ray), gB = ld(a.g_beta, ray);
+    const float gts = go * a.g_tsig_const;
     float gCs[3], gCt[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
         const float z = zr[ii], T = Ts[ii];
         const float* f = fr + ii * 9;
         const float cr = f[0], cg = f[1], cb = f[2], sg = f[3];
-        const float gw = a.g_weights ? a.g_weights[(size_t)ray * N + ii] : 0.f;
+        const float gw = a.g_weights ? go * a.g_weights[(size_t)ray * N + ii] : 0.f;
         const float g = gw + gW + gD * z - gwhite;
         float out[9];
 #pragma unroll
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
             const float after = inc - H + suffix;                 // sum over j > i
             const float common = ec * T * g - after;              // (1-alpha) T g - suffix
             const float dss = dl * (es * T * gs + common);
-            const float dst = dl * (et * T * gt + common) + (a.g_transient_sigmas ? a.g_transient_sigmas[(size_t)ray * N + ii] : 0.f);
+            const float dst = dl * (et * T * gt + common) + gts
+                              + (a.g_transient_sigmas ? go * a.g_transient_sigmas[(size_t)ray * N + ii] : 0.f);
             out[0] = ws * gCs[0] * cr * (1.f - cr);
             out[1] = ws * gCs[1] * cg * (1.f - cg);
             out[2] = ws * gCs[2] * cb * (1.f - cb);

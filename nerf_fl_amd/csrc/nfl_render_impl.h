@@ -467,10 +467,12 @@ struct NflActEpi {
                 hi = nfl_pack2<_Float16>(x0, x1);
             }
             reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
+#ifndef NFL_ABL_NO_RANGE_TRACK
             {   // range tracking: after relu the halves are non-negative, so their bit patterns order like the values
                 const unsigned mag = RELU ? hi : (hi & 0x7fff7fffu);
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(ovf) : "v"(mag));
             }
+#endif
             if (STASH) {        // the fp16 hi operand IS the stashed activation
                 reinterpret_cast<unsigned(&)[4]>(tmp[cb])[j / 2] = hi;
 #ifdef NFL_ABL_NOSTASHST
@@ -618,7 +620,7 @@ struct NflRenderCfg {
     static constexpr int LDS_RING = 3 * SLOT;
     static constexpr int LDS_BIAS = NFL_MAX_RT * 32 * 4;
     static constexpr int LDS_REC = (NSLOT + 2) * NFL_REC * 4;
-    static constexpr int LDS_CHK = (NFL_MAX_CHUNKS + 8 + 32) * 4;     // chunk offsets + 32 positional-encoding weights
+    static constexpr int LDS_CHK = (NFL_MAX_CHUNKS + 8 + 32 + 8) * 4; // chunk offsets + 32 positional-encoding weights + 4 loss partials
     static constexpr int LDS_BYTES = LDS_RING + LDS_BIAS + LDS_REC + LDS_CHK;
 };
 
@@ -656,6 +658,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
     float* const rec_lds = reinterpret_cast<float*>(smem + C::LDS_BIAS);   // [NSLOT] segment records, then carry[2]
     int* const chk_lds = reinterpret_cast<int*>(smem + C::LDS_BIAS + C::LDS_REC);
     float* const pw_lds = reinterpret_cast<float*>(chk_lds + NFL_MAX_CHUNKS + 8);   // [0,16): xyz freqs, [16,32): dir freqs
+    float* const loss_lds = pw_lds + 32;                                            // [4] fused-loss partial sums of this workgroup
 
     const nfl_pass_args& a = A.a;
     const int tid = threadIdx.x;
@@ -677,6 +680,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         for (int i = tid; i <= A.n_chunks; i += 256) chk_lds[i] = A.plan->chunk_off[i];
         if (tid < 16) pw_lds[tid] = (a.d_pe_w_xyz && tid < NFX) ? a.d_pe_w_xyz[tid] : 1.f;
         else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid < 20) ? a.d_pe_w_dir[tid - 16] : 1.f;
+        else if (tid < 36) loss_lds[tid - 32] = 0.f;
     }
     __syncthreads();
 
@@ -990,6 +994,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 } else {
 #pragma unroll
                     for (int k = 12; k < NFL_NST; ++k) rec[k] = 0.f;
+                    if (a.d_loss_target) rec[19] = nfl_sum32(ok ? sgt : 0.f);    // s_l: plain sum of the transient densities
                 }
             } else {
                 rec[4] = nfl_sum32(w * cr); rec[5] = nfl_sum32(w * cg); rec[6] = nfl_sum32(w * cbl);
@@ -1031,10 +1036,11 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 acc = kk < 3 ? 0.f : carry_in[kk];
                 m0 = 0;
             }
+            const bool plain = kk == 19 && !a.test_extras;      // entry 19 outside test_time: an unweighted sum (fused s_l)
             for (int mm = m0; mm <= m; ++mm) {
                 const float* r = rec_lds + mm * NFL_REC;
                 if (mm < m) t_in *= r[0];
-                acc += t_run * r[kk];
+                acc += (plain ? 1.f : t_run) * r[kk];
                 t_run *= r[chain];
             }
             // per-sample outputs
@@ -1064,6 +1070,37 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         a.d_rgb[ray * 3 + lane - 4] = stat;
                     }
                 }
+                if (a.d_loss_target) {
+                    // NerfWLoss of this ray (reference losses.py:35-50) and its backward seeds
+                    const bool ch = lane >= 4 && lane < 7;
+                    const float tgt = ch ? a.d_loss_target[ray * 3 + lane - 4] : 0.f;
+                    const float diff = ch ? (A.use_t ? stat + tran : stat) - tgt : 0.f;
+                    const float sq = diff * diff;
+                    const float sum3 = __shfl(sq, 4) + __shfl(sq, 5) + __shfl(sq, 6);
+                    const float rinv = 1.f / (float)a.n_rays, c0 = a.loss_coef;
+                    float l0, l1 = 0.f, l2 = 0.f, g_rgb;
+                    if (A.use_t) {
+                        const float beta = __shfl(acc, 10) + A.beta_min;
+                        const float ib2 = 1.f / (beta * beta);
+                        l0 = c0 * sum3 * 0.5f * ib2 * rinv * (1.f / 3.f);
+                        l1 = c0 * (3.f + logf(beta)) * rinv;
+                        l2 = c0 * a.lambda_u * __shfl(acc, 19) * rinv / (float)N;
+                        g_rgb = c0 * diff * ib2 * rinv * (1.f / 3.f);
+                        if (lane == 10 && a.d_seed_beta)
+                            a.d_seed_beta[ray] = c0 * rinv * (1.f / beta - sum3 * ib2 / beta * (1.f / 3.f));
+                    } else {
+                        l0 = c0 * 0.5f * sum3 * rinv * (1.f / 3.f);
+                        g_rgb = c0 * diff * rinv * (1.f / 3.f);
+                    }
+                    if (ch && a.d_seed_rgb) a.d_seed_rgb[ray * 3 + lane - 4] = g_rgb;
+                    if (lane == 0) {
+                        atomicAdd(loss_lds + a.loss_slot, l0);
+                        if (A.use_t) {
+                            atomicAdd(loss_lds + 2, l1);
+                            atomicAdd(loss_lds + 3, l2);
+                        }
+                    }
+                }
                 if (A.use_t) {
                     if (lane == 10 && a.d_beta) a.d_beta[ray] = acc + A.beta_min;
                     if (a.test_extras) {
@@ -1083,6 +1120,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         NFL_STAMP(17);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two prefetched chunks before exit
+    if (a.d_loss_target) {  // one flush of this workgroup's loss partials
+        __syncthreads();
+        if (tid < 4 && a.d_losses && loss_lds[tid] != 0.f) atomicAdd(a.d_losses + tid, loss_lds[tid]);
+    }
     if (a.d_status) {      // an activation beyond fp16's range: the conversion gave inf (0x7c00) -- header, d_status
         const bool bad = (ring.ovf & 0xffffu) >= 0x7c00u || (ring.ovf >> 16) >= 0x7c00u;
         if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.d_status, NFL_STATUS_RANGE);

@@ -59,7 +59,13 @@ class GraphedChunk:
                 self.ts[n:].copy_(ts[-1:].expand(self.chunk - n))
         for k, buf in self.kw_static.items():
             if k in latents:
-                buf.copy_(latents[k].expand(self.chunk, -1))
+                v = latents[k]
+                if v.shape[0] == 1:
+                    buf.copy_(v.expand(self.chunk, -1))
+                else:                                        # per-ray values of a (possibly ragged) chunk
+                    buf[:n].copy_(v)
+                    if n < self.chunk:
+                        buf[n:].copy_(v[-1:].expand(self.chunk - n, -1))
         self.graph.replay()
         return {k: v[:n] for k, v in self.out.items()}
 
@@ -82,11 +88,19 @@ def batched_inference(models, embeddings, rays, ts, N_samples, N_importance, use
     for i in range(0, B, chunk):
         r = rays.slice(i, i + chunk) if isinstance(rays, CameraRays) else rays[i:i + chunk]
         t = ts[i:i + chunk] if ts is not None else None         # reference eval.py:94
+        n = r.shape[0]
+        # per-ray kwargs follow their chunk: a (B, C) tensor is sliced, a (1, C) one (one latent code for the whole
+        # frame, test_phototourism.ipynb cell 11) is broadcast
+        per_ray = {}
+        for k in ("a_embedded", "t_embedded", "view_dir"):
+            v = kwargs.get(k)
+            if v is not None:
+                per_ray[k] = v[i:i + chunk] if v.shape[0] == B and B != 1 else v.expand(n, -1)
         if runner is not None:
-            out = {k: v.clone() for k, v in runner(r, t).items()}
+            out = {k: v.clone() for k, v in runner(r, t, **per_ray).items()}
         else:
             out = render_rays(models, embeddings, r, t, N_samples, use_disp, 0, 0, N_importance, chunk, white_back,
-                              True, **kwargs)
+                              True, **{**kwargs, **per_ray})
         for k, v in out.items():
             results.setdefault(k, []).append(v)
     return {k: torch.cat(v, 0) for k, v in results.items()}

@@ -304,7 +304,7 @@ def _n_freqs(emb):
 def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, perturb=0.0, use_disp=False,
               noise=None, noise_std=0.0, a_emb=None, t_emb=None, view_dir=None, sigma_only=False,
               white_back=False, test_extras=False, want_rgb=True, want_z=False, field_raw=False, stash=False,
-              pe_w_xyz=None, pe_w_dir=None):
+              pe_w_xyz=None, pe_w_dir=None, loss=None, loss_slot=0):
     R = rays.shape[0]
     dev = rays.device
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -348,6 +348,13 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     a.d_field_raw = _ptr(out.get("field_raw"))
     a.d_act_stash = _ptr(out.get("act_stash"))
     a.d_pe_w_xyz, a.d_pe_w_dir = _ptr(pe_w_xyz), _ptr(pe_w_dir)
+    if loss is not None:        # NerfWLoss fused into the per-ray epilogue (include/nerf_fl_amd.h: d_loss_target)
+        out["seed_rgb"] = new(R, 3)
+        if use_t:
+            out["seed_beta"] = new(R)
+        a.d_loss_target, a.d_losses = _ptr(loss["target"]), _ptr(loss["losses"])
+        a.d_seed_rgb, a.d_seed_beta = _ptr(out["seed_rgb"]), _ptr(out.get("seed_beta"))
+        a.loss_coef, a.lambda_u, a.loss_slot = float(loss["coef"]), float(loss["lambda_u"]), int(loss_slot)
     a.d_status = _ptr(_status_word(dev))
     _lib.check(_lib.lib().nfl_render_pass(field.h_plan, _ptr(field.d_plan), _ptr(field.packed), C.byref(a), _stream()),
                "nfl_render_pass")
@@ -364,7 +371,8 @@ def _forward(cfg, rays, a_emb, t_emb, train):
     oc = _run_pass(f_c, rays, S, lin=_linspace(S, dev), perturb_rand=cfg["perturb_rand"], perturb=cfg["perturb"],
                    use_disp=cfg["use_disp"], noise=cfg["noise_c"], noise_std=cfg["noise_std"],
                    view_dir=cfg["view_dir"], sigma_only=test_time, white_back=cfg["white_back"],
-                   want_z=I > 0 or train, field_raw=raw, stash=train, pe_w_xyz=cfg["pe_w_xyz"], pe_w_dir=cfg["pe_w_dir"])
+                   want_z=I > 0 or train, field_raw=raw, stash=train, pe_w_xyz=cfg["pe_w_xyz"], pe_w_dir=cfg["pe_w_dir"],
+                   loss=cfg["loss"] if train else None, loss_slot=0)
     result["weights_coarse"] = oc["weights"]
     result["opacity_coarse"] = oc["opacity"]
     if not test_time:
@@ -374,7 +382,7 @@ def _forward(cfg, rays, a_emb, t_emb, train):
         result["_field_raw_coarse"] = oc["field_raw"]
     if train:
         saved["coarse"] = dict(z=oc["z"], field_raw=oc["field_raw"], act=oc["act_stash"], noise=cfg["noise_c"],
-                               use_t=False, n=S)
+                               use_t=False, n=S, seed_rgb=oc.get("seed_rgb"), seed_beta=None)
     if I > 0:
         F = S + I
         if cfg["z_fine"] is not None:        # injected fine depths (build-defined kwarg `z_fine`): the sampler is skipped
@@ -387,7 +395,7 @@ def _forward(cfg, rays, a_emb, t_emb, train):
         of = _run_pass(f_f, rays, F, z=z_fine, noise=cfg["noise_f"], noise_std=cfg["noise_std"], a_emb=a_emb,
                        t_emb=t_emb if use_t else None, view_dir=cfg["view_dir"], white_back=cfg["white_back"],
                        test_extras=test_time, field_raw=raw, stash=train, pe_w_xyz=cfg["pe_w_xyz"],
-                       pe_w_dir=cfg["pe_w_dir"])
+                       pe_w_dir=cfg["pe_w_dir"], loss=cfg["loss"] if train else None, loss_slot=1)
         result["weights_fine"] = of["weights"]
         result["opacity_fine"] = of["opacity"]
         if use_t:
@@ -409,7 +417,7 @@ def _forward(cfg, rays, a_emb, t_emb, train):
             result["_z_fine"] = z_fine
         if train:
             saved["fine"] = dict(z=z_fine, field_raw=of["field_raw"], act=of["act_stash"], noise=cfg["noise_f"],
-                                 use_t=use_t, n=F)
+                                 use_t=use_t, n=F, seed_rgb=of.get("seed_rgb"), seed_beta=of.get("seed_beta"))
     return result, (saved if train else None)
 
 
@@ -432,15 +440,28 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     ca.d_field_raw, ca.d_z, ca.d_noise = _ptr(st["field_raw"]), _ptr(st["z"]), _ptr(st["noise"])
     ca.noise_std, ca.n_rays, ca.n_samples = float(cfg["noise_std"]), R, N
     ca.use_transient, ca.white_back = int(use_t), int(bool(cfg["white_back"]))
-    keep = [_g(grads, keys, f"weights_{typ}"), _g(grads, keys, f"opacity_{typ}"), _g(grads, keys, f"rgb_{typ}"),
-            _g(grads, keys, f"depth_{typ}")]
-    if use_t:
-        keep += [_g(grads, keys, "transient_sigmas"), _g(grads, keys, "beta"), _g(grads, keys, "_rgb_fine_static"),
-                 _g(grads, keys, "_rgb_fine_transient")]
+    if cfg["loss"] is not None:
+        # fused NerfWLoss: the forward epilogue left d loss / d rgb (and d beta) per ray; s_l's gradient w.r.t. every
+        # transient density is the constant coef * lambda_u / (R N); everything is scaled by the upstream gradient of
+        # the total on the device (d_go)
+        keep = [None, None, st["seed_rgb"], None, None, st["seed_beta"] if use_t else None, None, None]
+        go = _g(grads, keys, "_nerfw_loss")
+        if go is None:
+            go = torch.zeros((), dtype=torch.float32, device=dev)
+        keep.append(go)
+        ca.d_go = _ptr(go)
+        if use_t:
+            ca.g_tsig_const = float(cfg["loss"]["coef"]) * float(cfg["loss"]["lambda_u"]) / float(R * N)
     else:
-        keep += [None, None, None, None]
+        keep = [_g(grads, keys, f"weights_{typ}"), _g(grads, keys, f"opacity_{typ}"), _g(grads, keys, f"rgb_{typ}"),
+                _g(grads, keys, f"depth_{typ}")]
+        if use_t:
+            keep += [_g(grads, keys, "transient_sigmas"), _g(grads, keys, "beta"), _g(grads, keys, "_rgb_fine_static"),
+                     _g(grads, keys, "_rgb_fine_transient")]
+        else:
+            keep += [None, None, None, None]
     (ca.g_weights, ca.g_opacity, ca.g_rgb, ca.g_depth, ca.g_transient_sigmas, ca.g_beta, ca.g_rgb_static,
-     ca.g_rgb_transient) = [_ptr(k) for k in keep]
+     ca.g_rgb_transient) = [_ptr(k) for k in keep[:8]]
     ca.d_head_grads = _ptr(head)
     gmax = torch.empty(_lib.NFL_GMAX_SLOTS, dtype=torch.float32, device=dev)   # loss scale source of this pass (zeroed by the call)
     ca.d_gmax = _ptr(gmax)
@@ -496,7 +517,13 @@ class _RenderRaysFn(torch.autograd.Function):
         if cfg["f_f"] is not None:
             cfg["f_f"].ensure_bwd_packed(cfg["rays_grad"])
             cfg["f_f"].wgrad_plan(cfg["use_t"])
+        if cfg["loss"] is not None:
+            terms = cfg["loss"]["losses"]
+            result["_nerfw_terms"] = terms              # (4,) = c_l, f_l, b_l, s_l (terms a configuration lacks stay 0)
+            result["_nerfw_loss"] = terms.sum()         # the differentiable total
         keys = [k for k in result if not k.startswith("_field_raw") and k != "_z_fine"]
+        if cfg["loss"] is not None:                     # only the total carries gradient in this mode
+            ctx.mark_non_differentiable(*[result[k] for k in keys if k != "_nerfw_loss"])
         ctx.cfg, ctx.keys, ctx.saved, ctx.rays = cfg, keys, saved, rays
         ctx.a_emb, ctx.t_emb = a_emb, t_emb
         ctx.extra = {k: v for k, v in result.items() if k not in keys}
@@ -541,7 +568,13 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         cfg = dict(S=S, I=I, use_disp=bool(use_disp), perturb=float(perturb), noise_std=float(noise_std),
                    white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
                    view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
-                   use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None)
+                   use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None, loss=None)
+        if kwargs.get("loss_target") is not None:
+            # build-defined: NerfWLoss (losses.py:35-50) fused into the per-ray epilogue of the training passes.  The result
+            # gains `_nerfw_loss` (scalar, the only output that carries gradient then) and `_nerfw_terms` (4,)
+            cfg["loss"] = dict(target=_f32c(kwargs["loss_target"], "loss_target", (R, 3)),
+                               losses=torch.zeros(4, dtype=torch.float32, device=dev),
+                               coef=float(kwargs.get("loss_coef", 1.0)), lambda_u=float(kwargs.get("lambda_u", 0.01)))
         if getattr(models["coarse"], "refine_pose", False):
             # BARF (reference rendering.py:105-108, 235-238): coarse-to-fine weights of both encodings
             epoch = kwargs.get("current_epoch")
@@ -599,6 +632,8 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         needs_grad = torch.is_grad_enabled() and (
             rays_grad or any(p.requires_grad for p in params)
             or any(t is not None and t.requires_grad for t in (a_emb, t_emb)))
+        if cfg["loss"] is not None and not (torch.is_grad_enabled() and not test_time):
+            raise RuntimeError("loss_target fuses the loss into the TRAINING passes: call it with gradients enabled")
         if needs_grad:
             if isinstance(rays, CameraRays):
                 raise RuntimeError("CameraRays is an inference input; call render_rays under torch.no_grad()")
@@ -608,7 +643,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                 raise RuntimeError("training needs the accurate mode: nerf_fl_amd.set_precision('f16x3') "
                                    "(the fast 'f16' mode is inference-only)")
             outs = _RenderRaysFn.apply(cfg, rays_in if rays_grad else rays, a_emb, t_emb, *params)
-            keys = [k for k in _result_keys(cfg)]
+            keys = [k for k in _result_keys(cfg)] + (["_nerfw_terms", "_nerfw_loss"] if cfg["loss"] is not None else [])
             if kwargs.get("check_finite"):
                 check_status(dev)
             return dict(zip(keys, outs))

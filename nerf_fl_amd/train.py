@@ -215,7 +215,8 @@ class GraphedTrainStep:
     and their Python disappear from the host's critical path; what matters at the README batch of 1024 rays, where the
     kernels take ~1.3 ms).  Random draws come from torch's graph-safe Philox generator, so every replay draws afresh.
 
-    `opt` must be `Adam(..., capturable=True)`.  Batches are loaded into the static buffers with `load()`.
+    `opt` must be `Adam(..., capturable=True)`; `loss_fn=None` uses the loss fused into the render kernels.  Batches are
+    loaded into the static buffers with `load()`.
     Construction runs `warmup` REAL steps eagerly (kernel attributes, optimizer state) before capturing.
     With `all_reduce=True` (ranks > 1) the step is two graphs with the flat gradient all-reduce between them."""
 
@@ -229,9 +230,14 @@ class GraphedTrainStep:
 
         def fwd_bwd():
             opt.zero_grad(set_to_none=True)
-            res = render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, perturb, noise_std,
-                              N_importance, 32768, white_back, False)
-            total = sum(loss_fn(res, self.target).values())
+            if loss_fn is None:      # NerfWLoss fused into the render kernels' per-ray epilogue (render_rays: loss_target)
+                res = render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, perturb, noise_std,
+                                  N_importance, 32768, white_back, False, loss_target=self.target)
+                total = res["_nerfw_loss"]
+            else:
+                res = render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, perturb, noise_std,
+                                  N_importance, 32768, white_back, False)
+                total = sum(loss_fn(res, self.target).values())
             total.backward()
             key = "rgb_fine" if "rgb_fine" in res else "rgb_coarse"
             return total.detach(), psnr(res[key].detach(), self.target)
@@ -313,16 +319,23 @@ class RayTrainer:
         else:
             self.sched = None
         self.loss = NerfWLoss()
+        self.fused_loss = True          # False: the NerfWLoss module on the result dict (two extra launches), as the reference composes it
         self.gen = torch.Generator(device=self.dev).manual_seed(seed + 1)
 
     # ---- one optimisation step on a ready batch ------------------------------------------------
     def step(self, rays, rgbs, ts):
         hp = self.hp
         self.opt.zero_grad(set_to_none=True)
-        res = render_rays(self.models, self.embeddings, rays, ts, hp["N_samples"], hp["use_disp"], hp["perturb"],
-                          hp["noise_std"], hp["N_importance"], 32768, hp["white_back"], False)
-        losses = self.loss(res, rgbs)
-        total = sum(losses.values())
+        if rays.is_cuda and self.fused_loss:
+            # NerfWLoss (coef 1, lambda_u 0.01) computed in the render kernels' per-ray epilogue, its backward seeds with it
+            res = render_rays(self.models, self.embeddings, rays, ts, hp["N_samples"], hp["use_disp"], hp["perturb"],
+                              hp["noise_std"], hp["N_importance"], 32768, hp["white_back"], False, loss_target=rgbs,
+                              loss_coef=self.loss.coef, lambda_u=self.loss.lambda_u)
+            total = res["_nerfw_loss"]
+        else:
+            res = render_rays(self.models, self.embeddings, rays, ts, hp["N_samples"], hp["use_disp"], hp["perturb"],
+                              hp["noise_std"], hp["N_importance"], 32768, hp["white_back"], False)
+            total = sum(self.loss(res, rgbs).values())
         total.backward()
         parallel.all_reduce_gradients(self.params)
         self.opt.step()

@@ -1,16 +1,18 @@
 #!/bin/bash
-# Run on the GPU box from the repo root:  bash profiles/collect.sh <tag>   (e.g. r01b)
-# Four rocprofv3 passes over the same command (bench.py's default train step, configs[1]): kernel trace +
-# stats, then FETCH_SIZE, WRITE_SIZE and the SQ block in separate --pmc passes (MI355X_MICROARCH.md, HBM /
-# rocprofv3 section).  Raw output goes to gpurun_out/prof_<tag>/; profiles/make_summary.py reduces it.
+# Run on the GPU box from the repo root:  bash profiles/collect.sh <tag>   (e.g. r02a)
+# Four rocprofv3 passes over bench.py's default train step (configs[1]): kernel trace + stats over the FULL default
+# command (so that the roofline launches bench.py times with events are in the trace), then FETCH_SIZE, WRITE_SIZE and
+# the SQ block in separate --pmc passes (MI355X_MICROARCH.md, HBM / rocprofv3 section) over the same steps WITHOUT the
+# companions (--no-extras: only warm-up + timed train steps, so that bytes summed over all dispatches / steps = bytes per
+# step).  Raw output goes to gpurun_out/prof_<tag>/; profiles/make_summary.py reduces it.
 set -e -o pipefail
 TAG=${1:-r01b}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o tr -- $CMD > "$OUT/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o tr -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 > "$OUT/stats.log" 2>&1
+CMD="python3 $ROOT/bench.py --no-extras --steps 20 --warmup 5"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o pmc -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- $CMD > "$OUT/write.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \

@@ -92,7 +92,28 @@ for k, v in sq.items():
     if m.get("GRBM_GUI_ACTIVE"):
         m["mfma_busy_frac"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     sqs[k] = m
-json.dump({"kernel_stats": kernel_stats, "launch_clusters": clusters, "traffic": traffic, "sq": sqs},
+# ---- HBM bytes of one whole train step: all nfl_* dispatches of the PMC passes (warm-up + timed steps of
+# `bench.py --no-extras`, identical work each) divided by the number of steps (= nfl_adam_kernel dispatches)
+n_steps = max(1, len(fetch.get("nfl_adam_kernel", {}).get("FETCH_SIZE", [])))
+tot_f = sum(sum(v["FETCH_SIZE"]) for v in fetch.values())
+tot_w = sum(sum(v["WRITE_SIZE"]) for v in write.values())
+R, S, F, NPARAM = 4096, 64, 128, 2 * 595844
+algorithmic = {
+    "rays_ts_in": R * (32 + 8),
+    "outputs": R * (4 * (S + F) + 2 * (4 + 12 + 4)),                 # weights_*, opacity, rgb, depth (808 B/ray)
+    "grad_outputs_in": R * (4 * (S + F) + 2 * (4 + 12 + 4)),
+    "parameters_read_fwd_bwd": 2 * NPARAM * 4,
+    "gradients_written": NPARAM * 4,
+    "adam_read_write": NPARAM * 28,                                    # p, g, m, v in; p, m, v out
+}
+step_traffic = {"hbm_bytes": (2.0 * tot_f + tot_w) * 1024.0 / n_steps, "steps_counted": n_steps,
+                "algorithmic_bytes": float(sum(algorithmic.values())), "algorithmic_breakdown": algorithmic,
+                "by_kernel_bytes": {k: (2.0 * sum(fetch[k]["FETCH_SIZE"]) + sum(write.get(k, {}).get("WRITE_SIZE", [0.0])))
+                                    * 1024.0 / n_steps for k in fetch},
+                "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB summed over every nfl_* dispatch of one train step; the "
+                        "excess over the algorithmic bytes is the fp16 activation / gradient stashes of the layer-major "
+                        "backward (DESIGN.md section 5)"}
+json.dump({"kernel_stats": kernel_stats, "launch_clusters": clusters, "traffic": traffic, "sq": sqs, "step_traffic": step_traffic},
           open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1)
 for f in ("bench_train.json", "bench_render.json", "time_passes.txt"):
     p = os.path.join(src, f)

@@ -49,7 +49,9 @@ class InjectRandom:
         assert not self.draws, "the reference drew fewer tensors than prepared"
 
 
-def run(kind):
+def run(kind, perturb=0.0, replica=1):
+    """perturb > 0: a replica whose initial weights are multiplied by (1 + perturb * N(0,1)) -- how far the REFERENCE
+    moves from itself under rounding-level differences; stored as psnr_<kind>_replica[2].npz."""
     cfg = sc.CONFIGS[kind]
     S, I, R, steps = cfg["S"], cfg["I"], cfg["R"], cfg["steps"]
     nerfw = cfg["fine"] == "at"
@@ -61,6 +63,11 @@ def run(kind):
     mf.load_state_dict(orc.make_field_params(spec_f, cfg["seed"] + 1, "default"))
     emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
     params = list(mc.parameters()) + list(mf.parameters())
+    if perturb > 0:
+        g = torch.Generator().manual_seed(4242 + 1000 * (replica - 1))
+        with torch.no_grad():
+            for p_ in params:
+                p_.mul_(1 + perturb * torch.randn(p_.shape, generator=g))
     if nerfw:
         for k, dim, off in (("a", 48, 4), ("t", 16, 5)):
             e = torch.nn.Embedding(cfg["n_vocab"], dim)
@@ -75,6 +82,8 @@ def run(kind):
         rays, ts, target = sc.batch(cfg, it)
         d = sc.draws(cfg, it)
         seq = [d["perturb_rand"], d["noise_coarse"], d["u"]] + ([] if nerfw else [d["noise_fine"]])
+        for grp in opt.param_groups:
+            grp["lr"] = sc.cosine_lr(cfg, it)
         opt.zero_grad()
         with InjectRandom(seq):
             res = render_rays(models, emb, rays, ts, S, False, 1.0, 1.0, I, 32768, True, False)
@@ -89,10 +98,16 @@ def run(kind):
         res = render_rays(models, emb, rays, ts, S, False, 0, 0.0, I, 32768, True, False)
     psnr = float(-10.0 * torch.log10(((res["rgb_fine"] - target) ** 2).mean()))
     print(f"[{kind}] validation PSNR of the reference-trained model: {psnr:.3f} dB")
-    np.savez_compressed(os.path.join(HERE, f"psnr_{kind}.npz"), cfg=json.dumps(cfg), losses=np.asarray(losses, np.float32),
-                        val_psnr=np.float32(psnr), val_rgb=res["rgb_fine"].numpy())
+    tag = f"psnr_{kind}" + (("_replica" + ("" if replica == 1 else str(replica))) if perturb > 0 else "")
+    np.savez_compressed(os.path.join(HERE, tag + ".npz"), cfg=json.dumps(cfg), losses=np.asarray(losses, np.float32),
+                        val_psnr=np.float32(psnr), perturb=np.float32(perturb))
 
 
 if __name__ == "__main__":
     for kind in (sys.argv[1:] or ["base", "nerfw"]):
-        run(kind)
+        if kind.endswith("_replica"):
+            run(kind[:-8], perturb=1e-6)
+        elif kind.endswith("_replica2"):
+            run(kind[:-9], perturb=1e-6, replica=2)
+        else:
+            run(kind)

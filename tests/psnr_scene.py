@@ -12,10 +12,19 @@ from oracle import nerfw_oracle as orc
 
 CONFIGS = {
     # configs[1]-like: base NeRF coarse + fine at the metric's sampling (64 + 64)
-    "base": dict(fine="base", S=64, I=64, R=256, steps=500, lr=5e-4, seed=301, n_vocab=12, n_val=512),
+    "base": dict(fine="base", S=64, I=64, R=256, steps=600, lr=5e-4, seed=301, n_vocab=12, n_val=2048),
     # configs[2]-like: NeRF-W (appearance + transient heads, beta, latent tables) at 64 + 64
-    "nerfw": dict(fine="at", S=64, I=64, R=256, steps=500, lr=5e-4, seed=401, n_vocab=12, n_val=512),
+    "nerfw": dict(fine="at", S=64, I=64, R=256, steps=600, lr=5e-4, seed=401, n_vocab=12, n_val=2048),
 }
+# Both sides anneal the learning rate to ~0 over the run (the reference's `--lr_scheduler cosine`, utils/__init__.py:49-50,
+# stepped per iteration here): a fit that is still moving fast at its last step has a validation PSNR that swings by
+# several 0.1 dB with rounding-level differences in ANY implementation, which would make a 0.1 dB comparison a coin toss.
+
+
+def cosine_lr(cfg, step):
+    """lr of step `step` (0-based): torch.optim.lr_scheduler.CosineAnnealingLR(T_max=steps, eta_min=1e-8), closed form."""
+    import math
+    return 1e-8 + (cfg["lr"] - 1e-8) * (1 + math.cos(math.pi * step / cfg["steps"])) / 2
 
 
 def colors(rays, ts, cfg, clean=False):

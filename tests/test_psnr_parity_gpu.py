@@ -75,7 +75,11 @@ def test_fit_psnr_matches_oracle():
 # same batches and random draws (tests/golden/make_psnr_ref.py -> tests/golden/psnr_*.npz hold its loss curve and
 # validation PSNR; tests/psnr_scene.py regenerates the inputs on both sides).
 # ---------------------------------------------------------------------------------------------------------------------
-LOSS_BAND = 0.05        # windowed mean (50 steps) of the training loss: HIP-trained within 5 % of reference-trained
+# How close can two correct implementations be?  Training is chaotic: the reference, re-run here with its initial
+# weights perturbed by 1e-6 relative (fp32 rounding level; psnr_*_replica*.npz), ends 0.1-0.2 dB away from ITSELF after
+# these 600 steps, and its windowed loss curve moves by ~2 %.  The test therefore allows 0.1 dB (BASELINE.json) on top of
+# the reference's own measured spread (largest pairwise difference among the reference run and its two replicas), and
+# for the loss curves twice the replicas' largest windowed deviation.
 
 
 @pytest.mark.parametrize("kind", ["base", "nerfw"])
@@ -116,6 +120,8 @@ def test_fit_psnr_matches_reference_64_64(kind):
         d = {k: v.to(dev) for k, v in sc.draws(cfg, it).items()}
         if nerfw:
             d.pop("noise_fine")          # the transient branch draws no density noise (rendering.py:146-149)
+        for grp in opt.param_groups:
+            grp["lr"] = sc.cosine_lr(cfg, it)
         opt.zero_grad(set_to_none=True)
         res = render_rays(models, emb, rays.to(dev), ts.to(dev), S, False, 1.0, 1.0, I, 32768, True, False, **d)
         loss = sum(loss_fn(res, target.to(dev)).values())
@@ -129,13 +135,18 @@ def test_fit_psnr_matches_reference_64_64(kind):
     psnr_hip = orc.psnr(out["rgb_fine"].cpu(), target)
     psnr_ref = float(ref["val_psnr"])
     win = 50
-    m_hip = losses[: steps // win * win].reshape(-1, win).mean(1)
-    m_ref = ref["losses"][: steps // win * win].reshape(-1, win).mean(1)
+    wmean = lambda x: np.asarray(x)[: steps // win * win].reshape(-1, win).mean(1)
+    m_hip, m_ref = wmean(losses), wmean(ref["losses"])
     dev_rel = np.abs(m_hip - m_ref) / np.abs(m_ref)
+    reps = [np.load(os.path.join(gu.GOLDEN_DIR, f"psnr_{kind}_replica{s}.npz"), allow_pickle=False) for s in ("", "2")]
+    psnrs = [psnr_ref] + [float(r["val_psnr"]) for r in reps]
+    spread = max(psnrs) - min(psnrs)
+    loss_spread = max(float((np.abs(wmean(r["losses"]) - m_ref) / np.abs(m_ref)).max()) for r in reps)
     print(f"[{kind}] validation PSNR: reference-trained {psnr_ref:.3f} dB, HIP-trained {psnr_hip:.3f} dB; first-step loss "
           f"{losses[0]:.6f} vs {ref['losses'][0]:.6f}; windowed loss curves differ by at most {100 * dev_rel.max():.2f} % "
-          f"(final window {m_hip[-1]:.5f} vs {m_ref[-1]:.5f})")
+          f"(final window {m_hip[-1]:.5f} vs {m_ref[-1]:.5f}); the reference's own replicas: PSNR {psnrs[1]:.3f} / {psnrs[2]:.3f} dB "
+          f"(spread {spread:.3f} dB), windowed loss deviation {100 * loss_spread:.2f} %")
     assert abs(float(losses[0]) - float(ref["losses"][0])) <= 1e-4 * max(1.0, abs(float(ref["losses"][0]))), "same first step"
     assert psnr_ref > 15.0, "the reference fit did not learn anything; the comparison would be vacuous"
-    assert abs(psnr_ref - psnr_hip) <= 0.1
-    assert dev_rel.max() <= LOSS_BAND
+    assert abs(psnr_ref - psnr_hip) <= 0.1 + spread
+    assert dev_rel.max() <= max(0.02, 2.0 * loss_spread)
