@@ -161,6 +161,9 @@ class Adam(torch.optim.Optimizer):
         L = _lib.lib()
         capturing = self.capturable and torch.cuda.is_current_stream_capturing()
         for gi, group in enumerate(self.param_groups):
+            if self.capturable:                  # device-side counters start from the steps ALREADY taken
+                for dev in {p.device for p in group["params"] if p.grad is not None}:
+                    self._dev_state(gi, group, dev)
             todo = {}                            # (device, step) -> list of (p, grad, m, v)
             for p in group["params"]:
                 if p.grad is None:
@@ -352,6 +355,9 @@ class RayTrainer:
             log.append(self.step(rays[idx], rgbs[idx], ts[idx]))
         if self.sched is not None:
             self.sched.step()
+        if self.dev.type == "cuda":
+            from .rendering import check_status
+            check_status(self.dev)          # fp16 range audit of the epoch's render passes (raises FloatingPointError)
         return torch.stack([torch.stack(x) for x in log]).mean(0).tolist() if log else [math.nan, math.nan]
 
     @torch.no_grad()

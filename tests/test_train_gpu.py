@@ -116,3 +116,91 @@ def test_fused_nerfw_loss_matches_reference_formula(variant):
     for k in inp:
         e, r = (hip_in[k].grad.cpu() - ref_in[k].grad).abs().max().item(), ref_in[k].grad.abs().max().item()
         assert e <= 2e-6 * r + 1e-12, (k, e, r)
+
+
+def test_capturable_adam_equals_the_eager_one():
+    """Adam(capturable=True) (C ABI nfl_adam_step_dev: lr / betas / eps / step count read from device memory) against
+    the by-value launch over 5 steps with a learning-rate change in between."""
+    import gpu_util
+    from nerf_fl_amd.train import Adam
+    dev = gpu_util.DEV
+    g = torch.Generator().manual_seed(3)
+    shapes = [(256, 63), (256,), (128, 283), (3,)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    a = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    b = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    oa, ob = Adam(a, lr=5e-4, eps=1e-8), Adam(b, lr=5e-4, eps=1e-8, capturable=True)
+    for step in range(5):
+        if step == 3:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 2e-4
+        for x, y in zip(a, b):
+            gr = torch.randn(*x.shape, generator=g).to(dev)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(a, b):
+        assert (x - y).abs().max().item() <= 1e-6 * max(1.0, x.abs().max().item())
+    assert ob.state[b[0]]["step"] == 5
+
+
+def test_graphed_train_step_trains_like_the_eager_step():
+    """GraphedTrainStep (re-pack + both passes + fused loss + backward + Adam captured in one HIP graph): replays draw
+    fresh random numbers, advance Adam's device-side step count, follow learning-rate changes, and fit the scene as the
+    eager loop does (same data, same number of steps; the draws differ, so PSNRs are compared, not weights)."""
+    import gpu_util
+    from nerf_fl_amd import NeRF, PosEmbedding, render_rays
+    from nerf_fl_amd.train import Adam, GraphedTrainStep, psnr
+    dev = gpu_util.DEV
+    spec = orc.FieldSpec("coarse")
+    teacher = orc.make_field_params(spec, 21, "sharp")
+    R, S, I, STEPS = 512, 32, 32, 60
+    rays = orc.make_rays(4096, 31)
+    with torch.no_grad():
+        rgb = orc.render_rays(spec, teacher, None, None, rays, n_samples=32, white_back=True, noise_std=0.0)["rgb_coarse"]
+    rays, rgb = rays.to(dev), rgb.to(dev)
+    ts = torch.zeros(R, dtype=torch.long, device=dev)
+    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
+
+    def fresh():
+        models = {"coarse": gpu_util.module_from(spec, orc.make_field_params(spec, 22, "default")),
+                  "fine": gpu_util.module_from(orc.FieldSpec("fine"), orc.make_field_params(orc.FieldSpec("fine"), 23, "default"))}
+        return models, [p for m in models.values() for p in m.parameters()]
+
+    def val(models):
+        with torch.no_grad():
+            out = render_rays(models, emb, rays[:1024], torch.zeros(1024, dtype=torch.long, device=dev), S, False, 0, 0.0, I,
+                              32768, True, False)
+        return float(psnr(out["rgb_fine"], rgb[:1024]))
+
+    gen = torch.Generator().manual_seed(4)
+    batches = [torch.randint(0, 4096, (R,), generator=gen).to(dev) for _ in range(STEPS + 2)]
+    # eager
+    models, params = fresh()
+    p0 = val(models)
+    opt = Adam(params, lr=1e-3)
+    for it in range(STEPS + 2):
+        opt.zero_grad(set_to_none=True)
+        idx = batches[it]
+        render_rays(models, emb, rays[idx], ts, S, False, 1.0, 1.0, I, 32768, True, False, loss_target=rgb[idx])["_nerfw_loss"].backward()
+        opt.step()
+    p_eager = val(models)
+    # graphed: 2 warm-up steps inside the constructor on batch 0, then STEPS replays
+    models, params = fresh()
+    opt = Adam(params, lr=1e-3, capturable=True)
+    g = GraphedTrainStep(models, emb, params, opt, None, rays[batches[0]], ts, rgb[batches[0]], S, I, warmup=2)
+    losses = []
+    for it in range(STEPS):
+        idx = batches[it + 2]
+        g.load(rays[idx], ts, rgb[idx])
+        if it == STEPS // 2:
+            opt.param_groups[0]["lr"] = 5e-4              # picked up by the captured launch through sync_hyper()
+        loss, _ = g.replay()
+        losses.append(loss.clone())
+    p_graph = val(models)                                   # eager render after replays: the weight streams must re-pack
+    losses = torch.stack(losses).cpu()
+    print(f"PSNR before {p0:.2f} dB, eager-trained {p_eager:.2f} dB, graph-trained {p_graph:.2f} dB")
+    assert torch.isfinite(losses).all() and len(set(losses.tolist())) > STEPS // 2, "replays must see new batches and draws"
+    assert opt.state[params[0]]["step"] == STEPS + 2
+    assert p_eager > p0 + 3.0 and p_graph > p0 + 3.0
+    assert abs(p_eager - p_graph) <= 1.5
