@@ -60,7 +60,8 @@ NFL_DEV void nfl_static_for(F&& f) {
 
 // ray of pixel p of a frame (reference datasets/ray_utils.py:5-55); the ONE implementation behind nfl_gen_rays and the
 // render kernel's camera prologue, so that both produce the same bits
-NFL_DEV void nfl_cam_ray(const nfl_camera& c, long long p, f4v& r0, f4v& r1) {
+template <class Cam>
+NFL_DEV void nfl_cam_ray(const Cam& c, long long p, f4v& r0, f4v& r1) {
     const float i = (float)(p % c.width), j = (float)(p / c.width);
     const float dx = (i - c.cx) / c.fx, dy = -(j - c.cy) / c.fy, dz = -1.f;
     float d[3];
@@ -573,13 +574,15 @@ NFL_DEV void nfl_head(Ring& ring, const float* bias_lds, int& rt, int h,
 // ---------------------------------------------------------------------------------
 // depths (reference models/rendering.py:243-259); every operation separately rounded
 // ---------------------------------------------------------------------------------
-NFL_DEV float nfl_z_plain(const nfl_pass_args& a, float near, float far, int i) {
+template <class PA>
+NFL_DEV float nfl_z_plain(const PA& a, float near, float far, int i) {
     const float s = a.d_lin[i];
     const float oms = 1.0f - s;
     if (!a.use_disp) return near * oms + far * s;
     return 1.0f / (1.0f / near * oms + 1.0f / far * s);
 }
-NFL_DEV float nfl_z_at(const nfl_pass_args& a, int ray, float near, float far, int i) {
+template <class PA>
+NFL_DEV float nfl_z_at(const PA& a, int ray, float near, float far, int i) {
     const int N = a.n_samples;
     if (a.d_z) return a.d_z[(size_t)ray * N + i];
     float z = nfl_z_plain(a, near, far, i);
@@ -643,6 +646,23 @@ extern "C" int nfl_debug_stamps(unsigned long long* host, int n_entries) {
 #define NFL_STAMP(i) do {} while (0)
 #endif
 
+#ifdef NFL_ABL_NO_LOSS
+#define NFL_LOSS_ON(a) false
+#else
+#define NFL_LOSS_ON(a) ((a).d_loss_target != nullptr)
+#endif
+// The kernel's argument block, re-read from the kernarg segment.  Values loaded through the returned pointer cannot be
+// hoisted above the call (the empty asm makes the pointer opaque), so arguments that are only needed in the cold parts
+// of a tile (ray set-up, compositing, outputs, loss) are s_load'ed there instead of being kept in SGPRs -- or rather in
+// SGPR spill lanes of VGPRs -- across the whole MLP, where every register is spoken for.
+struct RenderArgs;
+typedef const __attribute__((address_space(4))) RenderArgs* NflKArgs;
+NFL_DEV NflKArgs nfl_kargs() {
+    NflKArgs p = (NflKArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 #define NFL_MODE_RENDER 0
 #define NFL_MODE_STASH 1      // render + fp16 activation stash for the backward
 #define NFL_MODE_EMBED 2      // NeRF.forward on already-encoded inputs (reference models/nerf.py:153-212): no
@@ -701,6 +721,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
     for (int tile = 0; tile < ntiles; ++tile) {
+        NflKArgs K = nfl_kargs();          // ray set-up: arguments loaded here, not carried through the MLP
         // ------------------------------------------------------------ per-sample setup
         int s_ray[NCB], s_idx[NCB];
         bool s_ok[NCB];
@@ -721,8 +742,8 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             if constexpr (EMBED) {
                 // point b = 32 * segment + c of an (n_points, row) matrix [xyz enc | dir enc (+a) | tau]
                 const int b = ray * 32 + c;
-                const bool pok = seg_ok && b < A.n_points;
-                const float* xr = a.d_embedded + (size_t)(b < A.n_points ? b : A.n_points - 1) * A.emb_stride;
+                const bool pok = seg_ok && b < K->n_points;
+                const float* xr = K->a.d_embedded + (size_t)(b < K->n_points ? b : K->n_points - 1) * K->emb_stride;
                 st[cb] = nullptr;
                 mst[cb] = nullptr;
                 s_ray[cb] = ray;
@@ -743,22 +764,25 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 continue;
             }
             f4v r0, r1;
-            if (A.gen_rays) {
-                nfl_cam_ray(A.cam, A.cam.pix0 + ray, r0, r1);
-            } else {
-                const float* rp = a.d_rays + (size_t)ray * 8;
+#ifndef NFL_ABL_NO_CAM
+            if (K->gen_rays) {
+                nfl_cam_ray(K->cam, K->cam.pix0 + ray, r0, r1);
+            } else
+#endif
+            {
+                const float* rp = K->a.d_rays + (size_t)ray * 8;
                 r0 = *reinterpret_cast<const f4v*>(rp);
                 r1 = *reinterpret_cast<const f4v*>(rp + 4);
             }
             const float near = r1[2], far = r1[3];
-            const float z = nfl_z_at(a, ray, near, far, ii);
-            const float zn = ii + 1 < N ? nfl_z_at(a, ray, near, far, ii + 1) : z;
+            const float z = nfl_z_at(K->a, ray, near, far, ii);
+            const float zn = ii + 1 < N ? nfl_z_at(K->a, ray, near, far, ii + 1) : z;
             // padded segments recompute (and re-store) the last real one: identical bytes, no branch
             // stash k-step image = [sample c][lane half h][8 values]: a sample's 16 features are 32 contiguous
             // bytes, which makes the weight-gradient kernel's transposed LDS reads conflict-free
-            st[cb] = STASH ? a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + (2 * c + h) * 16
+            st[cb] = STASH ? K->a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + (2 * c + h) * 16
                            : nullptr;
-            mst[cb] = STASH ? a.d_act_stash + nfl_msk_offset((size_t)a.n_rays * SPR, NKP)
+            mst[cb] = STASH ? K->a.d_act_stash + nfl_msk_offset((size_t)K->a.n_rays * SPR, NKP)
                                   + (size_t)(ray0 * SPR + gg) * (NFL_MSK_WORDS * 256) + lane * 16
                             : nullptr;
             s_ray[cb] = ray;
@@ -766,7 +790,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             s_ok[cb] = ok;
             s_z[cb] = z;
             s_dl[cb] = ii + 1 < N ? zn - z : 1e2f;
-            if (a.d_z_out && ok && h == 0) a.d_z_out[(size_t)ray * N + ii] = z;
+            if (K->a.d_z_out && ok && h == 0) K->a.d_z_out[(size_t)ray * N + ii] = z;
             float raw[3], th[3], tl[3];
             raw[0] = r0[0] + r0[3] * z;
             raw[1] = r0[1] + r1[0] * z;
@@ -781,6 +805,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         }
 
         // ------------------------------------------------------------ the field
+        K = nfl_kargs();
         int rt = 0;
         // raw head outputs of sample c (lane half 0); extracted at once so the 16-register
         // accumulator tiles die immediately
@@ -809,7 +834,8 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             for (int cb = 0; cb < NCB; ++cb) o_sig[cb] = hacc[cb][0];
         }
         NFL_STAMP(9);
-        if (!a.sigma_only) {
+        K = nfl_kargs();           // head-side arguments (view directions, latents): loaded after the trunk
+        if (!K->a.sigma_only) {
             nfl_dense<NP, NCB, 16, 0, false, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP), mst, 0);   // final (linear)
             NFL_STAMP(10);
             {
@@ -818,11 +844,11 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 for (int cb = 0; cb < NCB; ++cb) {
                     if constexpr (EMBED) {
                         const int b = s_ray[cb] * 32 + s_idx[cb];
-                        const float* xr = a.d_embedded + (size_t)(b < A.n_points ? b : A.n_points - 1) * A.emb_stride
+                        const float* xr = K->a.d_embedded + (size_t)(b < K->n_points ? b : K->n_points - 1) * K->emb_stride
                                           + 6 * NFX + 3;
 #pragma unroll
                         for (int ks = 0; ks < 5; ++ks) {
-                            if (ks >= 2 && !A.has_a) break;
+                            if (ks >= 2 && !K->has_a) break;
                             float v[8];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
@@ -834,15 +860,19 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         continue;
                     }
                     float raw[3], th[3], tl[3];
-                    if (A.gen_rays && !a.d_view_dir) {
+#ifndef NFL_ABL_NO_CAM
+                    if (K->gen_rays && !K->a.d_view_dir) {
+#else
+                    if (false) {
+#endif
                         f4v g0, g1;
-                        nfl_cam_ray(A.cam, A.cam.pix0 + s_ray[cb], g0, g1);
+                        nfl_cam_ray(K->cam, K->cam.pix0 + s_ray[cb], g0, g1);
                         raw[0] = g0[3];
                         raw[1] = g1[0];
                         raw[2] = g1[1];
                     } else {
-                        const float* dp = a.d_view_dir ? a.d_view_dir + (size_t)s_ray[cb] * 3
-                                                       : a.d_rays + (size_t)s_ray[cb] * 8 + 3;
+                        const float* dp = K->a.d_view_dir ? K->a.d_view_dir + (size_t)s_ray[cb] * 3
+                                                       : K->a.d_rays + (size_t)s_ray[cb] * 8 + 3;
 #pragma unroll
                         for (int k = 0; k < 3; ++k) raw[k] = dp[k];
                     }
@@ -853,8 +883,8 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     __builtin_amdgcn_sched_barrier(0);
                     nfl_pe_kstep<4, NP>(1, h, raw, th, tl, pw_lds + 16, D[1][cb], STASH ? sd + 1024 : nullptr);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (A.has_a) {
-                        const float* ap = a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;
+                    if (K->has_a) {
+                        const float* ap = K->a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;
 #pragma unroll
                         for (int ks = 0; ks < 3; ++ks) {
                             const f4v v0 = *reinterpret_cast<const f4v*>(ap + 16 * ks);
@@ -866,7 +896,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     }
                 }
                 NFL_STAMP(11);
-                if (A.has_a)
+                if (K->has_a)
                     nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
                 else
                     nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
@@ -883,14 +913,15 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 }
             }
             NFL_STAMP(13);
-            if (A.use_t) {
+            K = nfl_kargs();
+            if (K->use_t) {
                 h8 T[1][NCB][NP];
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     const int tb = s_ray[cb] * 32 + s_idx[cb];
-                    const float* tp = EMBED ? a.d_embedded + (size_t)(tb < A.n_points ? tb : A.n_points - 1) * A.emb_stride
-                                                  + 6 * NFX + 3 + 27 + (A.has_a ? 48 : 0) + 8 * h
-                                            : a.d_t_emb + (size_t)s_ray[cb] * 16 + 8 * h;
+                    const float* tp = EMBED ? K->a.d_embedded + (size_t)(tb < K->n_points ? tb : K->n_points - 1) * K->emb_stride
+                                                  + 6 * NFX + 3 + 27 + (K->has_a ? 48 : 0) + 8 * h
+                                            : K->a.d_t_emb + (size_t)s_ray[cb] * 16 + 8 * h;
                     float v[8];
                     if constexpr (EMBED) {          // rows of the encoded matrix are not 16-byte aligned
 #pragma unroll
@@ -920,6 +951,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
 
         NFL_STAMP(14);
         // ------------------------------------------------------------ compositing, phase 1
+        K = nfl_kargs();
         // (reference models/rendering.py:141-226).  Lanes 0..31 of each half own sample c.
         float w_loc[NCB], sig_t[NCB];
 #pragma unroll
@@ -929,31 +961,31 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             const size_t sidx = (size_t)s_ray[cb] * N + s_idx[cb];
             const float sg = nfl_softplus(o_sig[cb]);
             float cr = 0.f, cg = 0.f, cbl = 0.f, tr = 0.f, tg = 0.f, tb = 0.f, sgt = 0.f, bt = 0.f;
-            if (!a.sigma_only) {
+            if (!K->a.sigma_only) {
                 cr = nfl_sigmoid(o_rgb[cb][0]);
                 cg = nfl_sigmoid(o_rgb[cb][1]);
                 cbl = nfl_sigmoid(o_rgb[cb][2]);
             }
-            if (A.use_t) {
+            if (K->use_t) {
                 sgt = nfl_softplus(o_tr[cb][0]);
                 tr = nfl_sigmoid(o_tr[cb][1]);
                 tg = nfl_sigmoid(o_tr[cb][2]);
                 tb = nfl_sigmoid(o_tr[cb][3]);
                 bt = nfl_softplus(o_tr[cb][4]);
             }
-            if (a.d_field_raw && ok && h == 0) {
-                float* fr = a.d_field_raw + sidx * 9;
+            if (K->a.d_field_raw && ok && h == 0) {
+                float* fr = K->a.d_field_raw + sidx * 9;
                 fr[0] = cr; fr[1] = cg; fr[2] = cbl; fr[3] = sg;
                 fr[4] = tr; fr[5] = tg; fr[6] = tb; fr[7] = sgt; fr[8] = bt;
             }
             if constexpr (EMBED) continue;          // the field outputs are the result; nothing to composite
             float alpha, a_s = 0.f, a_t = 0.f;
-            if (A.use_t) {
+            if (K->use_t) {
                 a_s = 1.f - expf(-dl * sg);
                 a_t = 1.f - expf(-dl * sgt);
                 alpha = 1.f - expf(-dl * (sg + sgt));
             } else {
-                const float nz = a.d_noise ? a.d_noise[sidx] * a.noise_std : 0.f;
+                const float nz = K->a.d_noise ? K->a.d_noise[sidx] * K->a.noise_std : 0.f;
                 alpha = 1.f - expf(-dl * fmaxf(sg + nz, 0.f));
             }
             if (!ok) { alpha = 0.f; a_s = 0.f; a_t = 0.f; }
@@ -980,12 +1012,12 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             rec[0] = prod[0]; rec[1] = prod[1]; rec[2] = prod[2];
             rec[3] = nfl_sum32(w);
             rec[11] = nfl_sum32(w * z);
-            if (A.use_t) {
+            if (K->use_t) {
                 const float ws = a_s * exc[0], wt = a_t * exc[0];
                 rec[4] = nfl_sum32(ws * cr); rec[5] = nfl_sum32(ws * cg); rec[6] = nfl_sum32(ws * cbl);
                 rec[7] = nfl_sum32(wt * tr); rec[8] = nfl_sum32(wt * tg); rec[9] = nfl_sum32(wt * tb);
                 rec[10] = nfl_sum32(wt * bt);
-                if (a.test_extras) {
+                if (K->a.test_extras) {
                     const float ws1 = a_s * exc[1], wt1 = a_t * exc[2];
                     rec[12] = nfl_sum32(ws1 * cr); rec[13] = nfl_sum32(ws1 * cg); rec[14] = nfl_sum32(ws1 * cbl);
                     rec[15] = nfl_sum32(ws1 * z);
@@ -994,7 +1026,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 } else {
 #pragma unroll
                     for (int k = 12; k < NFL_NST; ++k) rec[k] = 0.f;
-                    if (a.d_loss_target) rec[19] = nfl_sum32(ok ? sgt : 0.f);    // s_l: plain sum of the transient densities
+                    if (NFL_LOSS_ON(K->a)) rec[19] = nfl_sum32(ok ? sgt : 0.f);    // s_l: plain sum of the transient densities
                 }
             } else {
                 rec[4] = nfl_sum32(w * cr); rec[5] = nfl_sum32(w * cg); rec[6] = nfl_sum32(w * cbl);
@@ -1015,6 +1047,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         NFL_STAMP(16);
 
         // ------------------------------------------------------------ compositing, phase 2
+        K = nfl_kargs();
         // fold the segments of each ray in order; lane k (< NFL_NST) carries record entry k
         const float* carry_in = rec_lds + (NSLOT + (tile & 1)) * NFL_REC;
         float* carry_out = rec_lds + (NSLOT + ((tile + 1) & 1)) * NFL_REC;
@@ -1036,7 +1069,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 acc = kk < 3 ? 0.f : carry_in[kk];
                 m0 = 0;
             }
-            const bool plain = kk == 19 && !a.test_extras;      // entry 19 outside test_time: an unweighted sum (fused s_l)
+            const bool plain = NFL_LOSS_ON(K->a) && kk == 19;      // entry 19 with the fused loss: an unweighted sum (s_l)
             for (int mm = m0; mm <= m; ++mm) {
                 const float* r = rec_lds + mm * NFL_REC;
                 if (mm < m) t_in *= r[0];
@@ -1046,68 +1079,68 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             // per-sample outputs
             if (s_ok[cb] && h == 0) {
                 const size_t sidx = (size_t)ray * N + s_idx[cb];
-                if (a.d_weights) a.d_weights[sidx] = w_loc[cb] * t_in;
-                if (A.use_t && a.d_transient_sigmas) a.d_transient_sigmas[sidx] = sig_t[cb];
+                if (K->a.d_weights) K->a.d_weights[sidx] = w_loc[cb] * t_in;
+                if (K->use_t && K->a.d_transient_sigmas) K->a.d_transient_sigmas[sidx] = sig_t[cb];
             }
             if (q == SPR - 1) {
                 // ray complete: lane k holds the composited quantity k
                 const float wsum = __shfl(acc, 3);
-                if (a.d_status) {       // fp16 operand range exceeded somewhere on this ray (header: d_status)
+                if (K->a.d_status) {       // fp16 operand range exceeded somewhere on this ray (header: d_status)
                     const bool bad = lane < NFL_NST && !(fabsf(acc) <= 3.0e38f);
-                    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.d_status, NFL_STATUS_NONFINITE);
+                    if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(K->a.d_status, NFL_STATUS_NONFINITE);
                 }
-                const float white = a.white_back ? 1.f - wsum : 0.f;
+                const float white = K->a.white_back ? 1.f - wsum : 0.f;
                 const float stat = acc + white;                  // meaningful on lanes 4..6 and 12..14
                 const float tran = __shfl(acc, (lane + 3) & 63); // lanes 4..6 read 7..9
-                if (lane == 3 && a.d_opacity) a.d_opacity[ray] = acc;
-                if (lane == 11 && a.d_depth) a.d_depth[ray] = acc;
+                if (lane == 3 && K->a.d_opacity) K->a.d_opacity[ray] = acc;
+                if (lane == 11 && K->a.d_depth) K->a.d_depth[ray] = acc;
                 if (lane >= 4 && lane < 7) {
-                    if (A.use_t) {
-                        if (a.d_rgb_static) a.d_rgb_static[ray * 3 + lane - 4] = stat;
-                        if (a.d_rgb_transient) a.d_rgb_transient[ray * 3 + lane - 4] = tran;
-                        if (a.d_rgb) a.d_rgb[ray * 3 + lane - 4] = stat + tran;
-                    } else if (a.d_rgb) {
-                        a.d_rgb[ray * 3 + lane - 4] = stat;
+                    if (K->use_t) {
+                        if (K->a.d_rgb_static) K->a.d_rgb_static[ray * 3 + lane - 4] = stat;
+                        if (K->a.d_rgb_transient) K->a.d_rgb_transient[ray * 3 + lane - 4] = tran;
+                        if (K->a.d_rgb) K->a.d_rgb[ray * 3 + lane - 4] = stat + tran;
+                    } else if (K->a.d_rgb) {
+                        K->a.d_rgb[ray * 3 + lane - 4] = stat;
                     }
                 }
-                if (a.d_loss_target) {
+                if (NFL_LOSS_ON(K->a)) {
                     // NerfWLoss of this ray (reference losses.py:35-50) and its backward seeds
                     const bool ch = lane >= 4 && lane < 7;
-                    const float tgt = ch ? a.d_loss_target[ray * 3 + lane - 4] : 0.f;
-                    const float diff = ch ? (A.use_t ? stat + tran : stat) - tgt : 0.f;
+                    const float tgt = ch ? K->a.d_loss_target[ray * 3 + lane - 4] : 0.f;
+                    const float diff = ch ? (K->use_t ? stat + tran : stat) - tgt : 0.f;
                     const float sq = diff * diff;
                     const float sum3 = __shfl(sq, 4) + __shfl(sq, 5) + __shfl(sq, 6);
-                    const float rinv = 1.f / (float)a.n_rays, c0 = a.loss_coef;
+                    const float rinv = 1.f / (float)K->a.n_rays, c0 = K->a.loss_coef;
                     float l0, l1 = 0.f, l2 = 0.f, g_rgb;
-                    if (A.use_t) {
-                        const float beta = __shfl(acc, 10) + A.beta_min;
+                    if (K->use_t) {
+                        const float beta = __shfl(acc, 10) + K->beta_min;
                         const float ib2 = 1.f / (beta * beta);
                         l0 = c0 * sum3 * 0.5f * ib2 * rinv * (1.f / 3.f);
                         l1 = c0 * (3.f + logf(beta)) * rinv;
-                        l2 = c0 * a.lambda_u * __shfl(acc, 19) * rinv / (float)N;
+                        l2 = c0 * K->a.lambda_u * __shfl(acc, 19) * rinv / (float)N;
                         g_rgb = c0 * diff * ib2 * rinv * (1.f / 3.f);
-                        if (lane == 10 && a.d_seed_beta)
-                            a.d_seed_beta[ray] = c0 * rinv * (1.f / beta - sum3 * ib2 / beta * (1.f / 3.f));
+                        if (lane == 10 && K->a.d_seed_beta)
+                            K->a.d_seed_beta[ray] = c0 * rinv * (1.f / beta - sum3 * ib2 / beta * (1.f / 3.f));
                     } else {
                         l0 = c0 * 0.5f * sum3 * rinv * (1.f / 3.f);
                         g_rgb = c0 * diff * rinv * (1.f / 3.f);
                     }
-                    if (ch && a.d_seed_rgb) a.d_seed_rgb[ray * 3 + lane - 4] = g_rgb;
+                    if (ch && K->a.d_seed_rgb) K->a.d_seed_rgb[ray * 3 + lane - 4] = g_rgb;
                     if (lane == 0) {
-                        atomicAdd(loss_lds + a.loss_slot, l0);
-                        if (A.use_t) {
+                        atomicAdd(loss_lds + K->a.loss_slot, l0);
+                        if (K->use_t) {
                             atomicAdd(loss_lds + 2, l1);
                             atomicAdd(loss_lds + 3, l2);
                         }
                     }
                 }
-                if (A.use_t) {
-                    if (lane == 10 && a.d_beta) a.d_beta[ray] = acc + A.beta_min;
-                    if (a.test_extras) {
-                        if (lane >= 12 && lane < 15 && a.d_rgb_static_only) a.d_rgb_static_only[ray * 3 + lane - 12] = stat;
-                        if (lane == 15 && a.d_depth_static_only) a.d_depth_static_only[ray] = acc;
-                        if (lane >= 16 && lane < 19 && a.d_rgb_transient_only) a.d_rgb_transient_only[ray * 3 + lane - 16] = acc;
-                        if (lane == 19 && a.d_depth_transient_only) a.d_depth_transient_only[ray] = acc;
+                if (K->use_t) {
+                    if (lane == 10 && K->a.d_beta) K->a.d_beta[ray] = acc + K->beta_min;
+                    if (K->a.test_extras) {
+                        if (lane >= 12 && lane < 15 && K->a.d_rgb_static_only) K->a.d_rgb_static_only[ray * 3 + lane - 12] = stat;
+                        if (lane == 15 && K->a.d_depth_static_only) K->a.d_depth_static_only[ray] = acc;
+                        if (lane >= 16 && lane < 19 && K->a.d_rgb_transient_only) K->a.d_rgb_transient_only[ray * 3 + lane - 16] = acc;
+                        if (lane == 19 && K->a.d_depth_transient_only) K->a.d_depth_transient_only[ray] = acc;
                     }
                 }
             } else if (m == NSLOT - 1) {
@@ -1120,13 +1153,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         NFL_STAMP(17);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the two prefetched chunks before exit
-    if (a.d_loss_target) {  // one flush of this workgroup's loss partials
+    NflKArgs K = nfl_kargs();
+    if (NFL_LOSS_ON(K->a)) {   // one flush of this workgroup's loss partials
         __syncthreads();
-        if (tid < 4 && a.d_losses && loss_lds[tid] != 0.f) atomicAdd(a.d_losses + tid, loss_lds[tid]);
+        if (tid < 4 && K->a.d_losses && loss_lds[tid] != 0.f) atomicAdd(K->a.d_losses + tid, loss_lds[tid]);
     }
-    if (a.d_status) {      // an activation beyond fp16's range: the conversion gave inf (0x7c00) -- header, d_status
+    if (K->a.d_status) {      // an activation beyond fp16's range: the conversion gave inf (0x7c00) -- header, d_status
         const bool bad = (ring.ovf & 0xffffu) >= 0x7c00u || (ring.ovf >> 16) >= 0x7c00u;
-        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(a.d_status, NFL_STATUS_RANGE);
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) atomicOr(K->a.d_status, NFL_STATUS_RANGE);
     }
 #ifdef NFL_STAMPS
     NFL_STAMP(18);

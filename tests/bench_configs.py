@@ -50,8 +50,7 @@ target, loss_fn = torch.rand(R, 3, device=dev), NerfWLoss()
 
 def train_step():
     opt.zero_grad(set_to_none=True)
-    res = render_rays(models, emb, rays, ts, 64, False, 1.0, 1.0, 64, 32768, True, False)
-    sum(loss_fn(res, target).values()).backward()
+    render_rays(models, emb, rays, ts, 64, False, 1.0, 1.0, 64, 32768, True, False, loss_target=target)["_nerfw_loss"].backward()
     opt.step()
 
 dt = timed(train_step, 30, 8)
@@ -66,4 +65,17 @@ for name, graph in (("direct", False), ("hip_graph", True)):
                                          use_graph=graph, _graph_cache=cache), 5, 2)
     out[f"cfg5_eval_{name}"] = {"ms_per_131072_rays": dt * 1e3, "ray_samples_per_s": R * 256 / dt,
                                 "rays_per_s": R / dt}
+# ---- one 800 x 800 frame from (pose, intrinsics): rays generated in the kernel prologue vs a materialised ray matrix
+from nerf_fl_amd.eval import fov60_intrinsics, frame_rays, render_frame
+from nerf_fl_amd.poses import make_c2w
+H = W = 800
+K = fov60_intrinsics(W, H)
+c2w = make_c2w(torch.tensor([0.0, 0.05, 0.0]), torch.tensor([0.0, 0.0, 4.0]))[:3]
+kw = dict(chunk=chunk, white_back=False, device=dev, output_transient=False)
+dt = timed(lambda: render_frame(models, emb, c2w, K, H, W, 0.3, 5.0, 128, 128, ts=7, **kw), 3, 1)
+out["cfg5_frame_800x800_camera_prologue"] = {"ms_per_frame": dt * 1e3, "rays_per_s": H * W / dt}
+ts_f = torch.full((H * W,), 7, dtype=torch.long, device=dev)
+dt = timed(lambda: batched_inference(models, emb, frame_rays(c2w, K, H, W, 0.3, 5.0, dev), ts_f, 128, 128, chunk=chunk,
+                                     white_back=False, output_transient=False), 3, 1)
+out["cfg5_frame_800x800_ray_matrix"] = {"ms_per_frame": dt * 1e3, "rays_per_s": H * W / dt}
 print(json.dumps(out, indent=1))

