@@ -35,6 +35,14 @@ struct DgradArgs {
     int rays_tiles;           // the stream carries the encoded-position / direction rows (gradient w.r.t. rays)
 };
 
+struct DgradArgs;
+typedef const __attribute__((address_space(4))) DgradArgs* NflDgKArgs;
+NFL_DEV NflDgKArgs nfl_dg_kargs() {
+    NflDgKArgs p = (NflDgKArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 template <int NFX>
 struct NflDgradCfg {
     static constexpr int NP = 1, NCB = DG_NCB;
@@ -424,6 +432,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
 #endif
 
     for (int tile = 0; tile < ntiles; ++tile) {
+        NflDgKArgs K = nfl_dg_kargs();      // arguments are re-read from the kernarg segment where they are used (nfl_render_impl.h: nfl_kargs)
         bool seg_ok[NCB];
         int ray[NCB];
         char* gst[NCB];
@@ -439,13 +448,13 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             const int i = (gg % SPR) * 32 + c;
             const bool ok = seg_ok[cb] && i < N;
             // padded segments (zero gradients) write to a scratch record past the end: no branch in the epilogue
-            gst[cb] = a.d_grad_stash + (size_t)(seg_ok[cb] ? ray0 * SPR + gg : A.n_seg_total) * NFL_GRD_SLOTS * 1024 + (2 * c + h) * 16;     // [sample][lane half][8] image, as the activation stash
+            gst[cb] = K->a.d_grad_stash + (size_t)(seg_ok[cb] ? ray0 * SPR + gg : K->n_seg_total) * NFL_GRD_SLOTS * 1024 + (2 * c + h) * 16;     // [sample][lane half][8] image, as the activation stash
             zs[cb] = 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) xth[cb][k] = xtl[cb][k] = dth[cb][k] = dtl[cb][k] = gx[cb][k] = gd[cb][k] = 0.f;
-            if (A.rays_tiles && a.d_g_rays) {
-                const float* rp = a.d_rays + (size_t)ray[cb] * 8;
-                zs[cb] = a.d_z[(size_t)ray[cb] * N + (i < N ? i : N - 1)];
+            if (K->rays_tiles && K->a.d_g_rays) {
+                const float* rp = K->a.d_rays + (size_t)ray[cb] * 8;
+                zs[cb] = K->a.d_z[(size_t)ray[cb] * N + (i < N ? i : N - 1)];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float dk = rp[3 + k];
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                     nfl_turns(dk, dth[cb][k], dtl[cb][k]);
                 }
             }
-            const float* hp = a.d_head_grads + ((size_t)ray[cb] * N + (i < N ? i : N - 1)) * 9;
+            const float* hp = K->a.d_head_grads + ((size_t)ray[cb] * N + (i < N ? i : N - 1)) * 9;
 #pragma unroll
             for (int k = 0; k < 9; ++k) hg[cb][k] = (ok && h == 0) ? hp[k] * scale : 0.f;
         }
@@ -483,32 +492,35 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         // the halves of Q, d(dir hidden) lands in Q[0..8) next to dg1 in Q[8..16), d(feat) in P, then the trunk
         // alternates Q, P, Q, ...
         h8 P[16][NCB][1], Q[16][NCB][1];
-        if (A.use_t) {
+        K = nfl_dg_kargs();
+        if (K->use_t) {
             dg_tiles<WB, true, 4, 1, 1, 1, NCB>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4));
             dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3));
             dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2));
             dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
             float* gt[NCB];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) gt[cb] = (a.d_g_t_emb && seg_ok[cb]) ? a.d_g_t_emb + (size_t)ray[cb] * 16 : nullptr;
+            for (int cb = 0; cb < NCB; ++cb) gt[cb] = (K->a.d_g_t_emb && seg_ok[cb]) ? K->a.d_g_t_emb + (size_t)ray[cb] * 16 : nullptr;
             dg_latent_tile<8, NCB>(ring, Q, 8, gt, 16, h, c, inv_scale);
         }
         dg_tiles<WB, true, 4, 1, 0, 0, NCB>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
-        if (A.has_a) {
+        K = nfl_dg_kargs();
+        if (K->has_a) {
             float* ga[NCB];
             float* ga2[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                ga[cb] = (a.d_g_a_emb && seg_ok[cb]) ? a.d_g_a_emb + (size_t)ray[cb] * 48 : nullptr;
+                ga[cb] = (K->a.d_g_a_emb && seg_ok[cb]) ? K->a.d_g_a_emb + (size_t)ray[cb] * 48 : nullptr;
                 ga2[cb] = ga[cb] ? ga[cb] + 32 : nullptr;
             }
             dg_latent_tile<8, NCB>(ring, Q, 0, ga, 32, h, c, inv_scale);
             dg_latent_tile<8, NCB>(ring, Q, 0, ga2, 16, h, c, inv_scale);
         }
-        if (A.rays_tiles) dg_pe_tile<4, 0, 8, NCB>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
-        if (A.use_t)
+        K = nfl_dg_kargs();
+        if (K->rays_tiles) dg_pe_tile<4, 0, 8, NCB>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
+        if (K->use_t)
             dg_tiles<WB, false, 8, 8, 8, 0, NCB>(ring, moff, Q, 0, Q, 8, Q, 0, P, 0, gst, NFL_GRD_FEAT);
-        else if (A.has_t)      // the stream's d(feat) tiles carry the transient segment too: read the first 8 k-steps of 16
+        else if (K->has_t)      // the stream's d(feat) tiles carry the transient segment too: read the first 8 k-steps of 16
             dg_tiles<WB, false, 8, 8, 0, 0, NCB, 16>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_FEAT);
         else
             dg_tiles<WB, false, 8, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_FEAT);
@@ -517,7 +529,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(6));
         dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(5));
         dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(4));
-        if (A.rays_tiles) {       // skip connection: delta_5 (still in P) reaches the encoded position too
+        K = nfl_dg_kargs();
+        if (K->rays_tiles) {       // skip connection: delta_5 (still in P) reaches the encoded position too
             dg_pe_tile<NFX, 0, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
             dg_pe_tile<NFX, 1, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
             if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
@@ -525,11 +538,11 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(3));
         dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(2));
         dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(1));
-        if (A.rays_tiles) {
+        if (K->rays_tiles) {
             dg_pe_tile<NFX, 0, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
             dg_pe_tile<NFX, 1, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
             if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
-            if (a.d_g_rays) {
+            if (K->a.d_g_rays) {
                 // x = o + d z ; the view direction is d itself (no caller passes view_dir with learnable poses)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
@@ -540,8 +553,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                         const float so = nfl_sum32(gxk) * inv_scale;
                         const float sd = nfl_sum32(gxk * zs[cb] + gdk) * inv_scale;
                         if (lane == 0 && seg_ok[cb]) {
-                            atomicAdd(a.d_g_rays + (size_t)ray[cb] * 8 + k, so);
-                            atomicAdd(a.d_g_rays + (size_t)ray[cb] * 8 + 3 + k, sd);
+                            atomicAdd(K->a.d_g_rays + (size_t)ray[cb] * 8 + k, so);
+                            atomicAdd(K->a.d_g_rays + (size_t)ray[cb] * 8 + 3 + k, sd);
                         }
                     }
             }
