@@ -59,6 +59,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true",
                     help="only the warm-up and the timed steps (no render-only companion, roofline launches or CPU baseline): "
                          "the command the PMC passes of profiles/collect.sh count bytes over")
+    ap.add_argument("--render-steps", type=int, default=0,
+                    help="with --no-extras: this many forward-only steps after the timed ones (gives the PMC passes the "
+                         "inference instantiation of the render kernel to count bytes on)")
     ap.add_argument("--dry", action="store_true")
     return ap.parse_args(argv)
 
@@ -316,6 +319,10 @@ def run_rank(args):
                    "mlp_evals_per_ray": N_SAMPLES + F, "hip_graph": bool(args.graph)},
     }
 
+    if args.no_extras:
+        for _ in range(args.render_steps):
+            render_step()
+        sync()
     if args.mode == "train" and not args.no_extras:
         # forward-only throughput of the same batch, reported beside the train-step value
         for _ in range(3):

@@ -4,9 +4,10 @@
 (by the reference's state_dict names, so reference checkpoints load unchanged)
 and attributes (`typ`, `encode_appearance`, `encode_transient`, `beta_min`,
 `in_channels_*`, reference models/nerf.py:104-119) and evaluates the field inside
-the fused HIP kernel.  forward() is provided only so code that calls a module
-directly (reference models/nerf.py:153-212, 19-32) keeps working; it is plain
-PyTorch and not on the measured path.
+the fused HIP kernel.  forward() exists so that code which calls a module
+directly (reference models/nerf.py:153-212, 19-32) keeps working: it runs the same
+HIP kernels through the C ABI (`nfl_field_forward`, `nfl_posenc`), is inference-only
+and raises on CPU tensors.
 """
 import math
 

@@ -12,7 +12,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o tr -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 5 > "$OUT/stats.log" 2>&1
-CMD="python3 $ROOT/bench.py --no-extras --steps 20 --warmup 5"
+CMD="python3 $ROOT/bench.py --no-extras --steps 20 --warmup 5 --render-steps 3"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o pmc -- $CMD > "$OUT/fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o pmc -- $CMD > "$OUT/write.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \

@@ -95,8 +95,11 @@ for k, v in sq.items():
 # ---- HBM bytes of one whole train step: all nfl_* dispatches of the PMC passes (warm-up + timed steps of
 # `bench.py --no-extras`, identical work each) divided by the number of steps (= nfl_adam_kernel dispatches)
 n_steps = max(1, len(fetch.get("nfl_adam_kernel", {}).get("FETCH_SIZE", [])))
-tot_f = sum(sum(v["FETCH_SIZE"]) for v in fetch.values())
-tot_w = sum(sum(v["WRITE_SIZE"]) for v in write.values())
+# the inference instantiation `<..., 0>` belongs to the forward-only companion steps (--render-steps), not to a train step;
+# their few nfl_pack / nfl_sample_pdf launches (28 MB each) are left in: 3 MB per step of 18 GB
+in_step = lambda k: not (k.startswith("nfl_render_kernel") and k.rstrip().endswith(", 0>"))
+tot_f = sum(sum(v["FETCH_SIZE"]) for k, v in fetch.items() if in_step(k))
+tot_w = sum(sum(v["WRITE_SIZE"]) for k, v in write.items() if in_step(k))
 R, S, F, NPARAM = 4096, 64, 128, 2 * 595844
 algorithmic = {
     "rays_ts_in": R * (32 + 8),
@@ -109,7 +112,7 @@ algorithmic = {
 step_traffic = {"hbm_bytes": (2.0 * tot_f + tot_w) * 1024.0 / n_steps, "steps_counted": n_steps,
                 "algorithmic_bytes": float(sum(algorithmic.values())), "algorithmic_breakdown": algorithmic,
                 "by_kernel_bytes": {k: (2.0 * sum(fetch[k]["FETCH_SIZE"]) + sum(write.get(k, {}).get("WRITE_SIZE", [0.0])))
-                                    * 1024.0 / n_steps for k in fetch},
+                                    * 1024.0 / n_steps for k in fetch if in_step(k)},
                 "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB summed over every nfl_* dispatch of one train step; the "
                         "excess over the algorithmic bytes is the fp16 activation / gradient stashes of the layer-major "
                         "backward (DESIGN.md section 5)"}
