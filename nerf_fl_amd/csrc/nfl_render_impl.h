@@ -46,6 +46,12 @@ __device__ __forceinline__ f16v nfl_mfma(b8 a, b8 b, f16v c) { return __builtin_
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 #define NFL_DEV __device__ __forceinline__
+// stash stores are streaming (nt): A/B on one box, training forward 1.69 ms with nt, 1.74 with plain stores (step 5.20 / 5.36 ms)
+#ifdef NFL_ABL_PLAIN_STASH
+#define NFL_STREAM_STORE(v, p) (*(p) = (v))
+#else
+#define NFL_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
 
 // compile-time loop: f(integral_constant<int, I>) for I in [I0, I1)
 template <int I0, int I1, class F>
@@ -188,7 +194,7 @@ NFL_DEV void nfl_stash8(const float (&v)[8], char* dst) {
     h8 t;
 #pragma unroll
     for (int j = 0; j < 8; j += 2) reinterpret_cast<unsigned(&)[4]>(t)[j / 2] = nfl_pack2<_Float16>(v[j], v[j + 1]);
-    __builtin_nontemporal_store(t, reinterpret_cast<h8*>(dst));
+    NFL_STREAM_STORE(t, reinterpret_cast<h8*>(dst));
 }
 
 // natural-order B operand of one k-step of a positional encoding: lane half h holds
@@ -363,7 +369,10 @@ NFL_DEV void nfl_lds_wait(nfl_u4 (&w)[NP]) {
 // DEPTH = how many k-steps ahead the fragments are read (DEPTH + 1 register sets).  Two k-steps are 6 MFMAs with
 // three products per k-step but only 2 with one: the single-product kernels read 4 ahead, or every k-step waits
 // out most of the LDS latency (in-kernel stamps: 3.3 k cycles per 32-MFMA row tile with DEPTH 2).
-template <int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring, int DEPTH = (NP == 1 ? 4 : 2)>
+#ifndef NFL_DEPTH_X3
+#define NFL_DEPTH_X3 2
+#endif
+template <int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring, int DEPTH = (NP == 1 ? 4 : NFL_DEPTH_X3)>
 NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& getb, Epi&& epi, Ring& ring) {
     constexpr int KSB = 1024 * NP;
     constexpr int NW = DEPTH + 1;
@@ -427,7 +436,9 @@ struct NflNoEpi {
     template <int K, int NK> NFL_DEV void step() {}
     NFL_DEV void early() {}
 };
+#ifndef NFL_EPI_EARLY
 #define NFL_EPI_EARLY 2      // pair-ops done before the first MFMA of the following tile
+#endif
 
 // Epilogue of an accumulator tile -> the two k-steps (ks, ks+1) of the next layer's B operand
 // (and, in the training forward, the fp16 activation stash), cut into 8 pair-ops per column
@@ -479,7 +490,7 @@ struct NflActEpi {
 #ifdef NFL_ABL_NOSTASHST
                 if (OP % 4 == 3) asm volatile("" :: "v"(tmp[cb]));
 #else
-                if (OP % 4 == 3) __builtin_nontemporal_store(tmp[cb], reinterpret_cast<h8*>(stash[cb] + (slot + s) * 1024));
+                if (OP % 4 == 3) NFL_STREAM_STORE(tmp[cb], reinterpret_cast<h8*>(stash[cb] + (slot + s) * 1024));
 #endif
                 if (RELU) {     // relu mask of the pair for the dgrad kernel: bit 2*OP / 16 + 2*OP (nfl_plan.h)
                     unsigned on;
@@ -493,7 +504,7 @@ struct NflActEpi {
                         if (MSLOT == 3) {
                             typedef unsigned nfl_mq4 __attribute__((ext_vector_type(4)));
                             const nfl_mq4 v = {mq[cb][0], mq[cb][1], mq[cb][2], mq[cb][3]};
-                            __builtin_nontemporal_store(v, reinterpret_cast<nfl_mq4*>(mstash[cb] + (mword >> 2) * 1024));
+                            NFL_STREAM_STORE(v, reinterpret_cast<nfl_mq4*>(mstash[cb] + (mword >> 2) * 1024));
                         }
 #endif
                     }
