@@ -263,6 +263,9 @@ typedef struct nfl_dgrad_args {
     int32_t reserved;
     float* d_g_a_emb;               /* (R,n_a)  accumulated into (zero it first) or NULL   */
     float* d_g_t_emb;               /* (R,n_tau) accumulated into (zero it first) or NULL  */
+    const int64_t* d_latent_row;    /* (R) or NULL.  When set, d_g_a_emb / d_g_t_emb are the gradients of the latent TABLES
+                                       (N_vocab, n_a) / (N_vocab, n_tau) and ray r accumulates into row d_latent_row[r] (= ts[r]):
+                                       the scatter-add of nn.Embedding's backward (rendering.py:276-286) happens in this kernel  */
     /* gradient w.r.t. the rays (needs a plan built with rays_grad = 1) */
     float* d_g_rays;                /* (R,8) accumulated into: columns 0..2 origin, 3..5 direction; 6,7 untouched; or NULL */
     const float* d_rays;            /* (R,8) as given to the forward pass                  */

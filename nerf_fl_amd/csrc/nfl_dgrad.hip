@@ -500,7 +500,10 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
             float* gt[NCB];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) gt[cb] = (K->a.d_g_t_emb && seg_ok[cb]) ? K->a.d_g_t_emb + (size_t)ray[cb] * 16 : nullptr;
+            for (int cb = 0; cb < NCB; ++cb) {
+                const size_t row = K->a.d_latent_row ? (size_t)K->a.d_latent_row[ray[cb]] : (size_t)ray[cb];     // table row or ray
+                gt[cb] = (K->a.d_g_t_emb && seg_ok[cb]) ? K->a.d_g_t_emb + row * 16 : nullptr;
+            }
             dg_latent_tile<8, NCB>(ring, Q, 8, gt, 16, h, c, inv_scale);
         }
         dg_tiles<WB, true, 4, 1, 0, 0, NCB>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
@@ -510,7 +513,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             float* ga2[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
-                ga[cb] = (K->a.d_g_a_emb && seg_ok[cb]) ? K->a.d_g_a_emb + (size_t)ray[cb] * 48 : nullptr;
+                const size_t row = K->a.d_latent_row ? (size_t)K->a.d_latent_row[ray[cb]] : (size_t)ray[cb];
+                ga[cb] = (K->a.d_g_a_emb && seg_ok[cb]) ? K->a.d_g_a_emb + row * 48 : nullptr;
                 ga2[cb] = ga[cb] ? ga[cb] + 32 : nullptr;
             }
             dg_latent_tile<8, NCB>(ring, Q, 0, ga, 32, h, c, inv_scale);

@@ -289,6 +289,12 @@ def posenc(x, n_freqs, weights=None):
     return out.reshape(*lead, 6 * n_freqs + 3)
 
 
+def _plain_embedding(e):
+    """An nn.Embedding whose backward is a plain dense scatter-add of the looked-up rows' gradients."""
+    return (isinstance(e, torch.nn.Embedding) and e.padding_idx is None and e.max_norm is None
+            and not e.scale_grad_by_freq and not e.sparse and e.weight.dtype == torch.float32 and e.weight.is_contiguous())
+
+
 def _linspace(n, device):
     k = (n, str(device))
     if k not in _lin_cache:
@@ -469,14 +475,17 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
 
     grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(field.desc), R, N), dtype=torch.uint8, device=dev)
     g_a = g_t = None
+    tables = cfg["latent_tables"]
     if want_latents and field.desc.encode_appearance:
-        g_a = torch.zeros(R, field.desc.n_a, dtype=torch.float32, device=dev)
+        g_a = torch.zeros(cfg["n_vocab_a"] if tables else R, field.desc.n_a, dtype=torch.float32, device=dev)
     if want_latents and use_t:
-        g_t = torch.zeros(R, field.desc.n_tau, dtype=torch.float32, device=dev)
+        g_t = torch.zeros(cfg["n_vocab_t"] if tables else R, field.desc.n_tau, dtype=torch.float32, device=dev)
     da = _lib.DgradArgs()
     da.d_head_grads, da.d_act_stash, da.d_grad_stash = _ptr(head), _ptr(st["act"]), _ptr(grad_stash)
     da.n_rays, da.n_samples, da.use_transient = R, N, int(use_t)
     da.d_g_a_emb, da.d_g_t_emb, da.d_gmax = _ptr(g_a), _ptr(g_t), _ptr(gmax)
+    if tables and want_latents:
+        da.d_latent_row = _ptr(cfg["ts"])       # the scatter-add into the table gradients happens in the kernel
     if g_rays is not None:
         da.d_g_rays, da.d_rays, da.d_z = _ptr(g_rays), _ptr(rays), _ptr(st["z"])
         da.d_pe_w_xyz, da.d_pe_w_dir = _ptr(cfg["pe_w_xyz"]), _ptr(cfg["pe_w_dir"])
@@ -510,8 +519,15 @@ class _RenderRaysFn(torch.autograd.Function):
     def forward(ctx, cfg, rays, a_emb, t_emb, *params):
         ctx.set_materialize_grads(False)     # outputs the loss does not use arrive as None, not as zero tensors to fill and read
         rays = _f32c(rays, "rays")
-        result, saved = _forward(cfg, rays, None if a_emb is None else _f32c(a_emb, "a_embedded"),
-                                 None if t_emb is None else _f32c(t_emb, "t_embedded"), train=True)
+        if cfg["latent_tables"]:          # a_emb / t_emb are the embedding tables: one gather each
+            a_rows = None if a_emb is None else a_emb.detach().index_select(0, cfg["ts"])
+            t_rows = None if t_emb is None else t_emb.detach().index_select(0, cfg["ts"])
+            cfg["n_vocab_a"] = 0 if a_emb is None else a_emb.shape[0]
+            cfg["n_vocab_t"] = 0 if t_emb is None else t_emb.shape[0]
+        else:
+            a_rows = None if a_emb is None else _f32c(a_emb, "a_embedded")
+            t_rows = None if t_emb is None else _f32c(t_emb, "t_embedded")
+        result, saved = _forward(cfg, rays, a_rows, t_rows, train=True)
         cfg["f_c"].ensure_bwd_packed(cfg["rays_grad"])
         cfg["f_c"].wgrad_plan(False)
         if cfg["f_f"] is not None:
@@ -568,7 +584,8 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         cfg = dict(S=S, I=I, use_disp=bool(use_disp), perturb=float(perturb), noise_std=float(noise_std),
                    white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
                    view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
-                   use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None, loss=None)
+                   use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None, loss=None,
+                   latent_tables=False, ts=None)
         if kwargs.get("loss_target") is not None:
             # build-defined: NerfWLoss (losses.py:35-50) fused into the per-ray epilogue of the training passes.  The result
             # gains `_nerfw_loss` (scalar, the only output that carries gradient then) and `_nerfw_terms` (4,)
@@ -611,16 +628,33 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
             fine = models["fine"]
             cfg["f_f"] = f_f = _field(fine, n_xyz, n_dir, dev)
             params += [p for _, w, b in f_f.param_list() for p in (w, b)]
-            if fine.encode_appearance:
-                a_emb = kwargs["a_embedded"] if "a_embedded" in kwargs else embeddings["a"](ts)
-                if tuple(a_emb.shape) != (R, f_f.desc.n_a):
-                    raise ValueError(f"a_embedded must be ({R}, {f_f.desc.n_a})")
             cfg["use_t"] = bool(kwargs.get("output_transient", True) and fine.encode_transient)
-            if cfg["use_t"]:
-                t_emb = kwargs["t_embedded"] if "t_embedded" in kwargs else embeddings["t"](ts)
-                if tuple(t_emb.shape) != (R, f_f.desc.n_tau):
-                    raise ValueError(f"t_embedded must be ({R}, {f_f.desc.n_tau})")
+            # Latent codes (rendering.py:276-286).  When every code in use comes from a plain nn.Embedding and a gradient
+            # is wanted, the autograd.Function takes the TABLES: the lookup is one gather and the backward's scatter-add
+            # into the (N_vocab, n) table gradient happens inside the dgrad kernel (nfl_dgrad_args::d_latent_row) instead
+            # of torch's embedding_backward (2 x 59 us at 1024 rays, 6 % of that step).
+            need_a, need_t = bool(fine.encode_appearance), cfg["use_t"]
+            from_table = {"a": need_a and "a_embedded" not in kwargs, "t": need_t and "t_embedded" not in kwargs}
+            cfg["latent_tables"] = bool(
+                torch.is_grad_enabled() and not test_time and (need_a or need_t)
+                and all(from_table[k] and _plain_embedding(embeddings[k]) and embeddings[k].weight.requires_grad
+                        for k, need in (("a", need_a), ("t", need_t)) if need))
+            if cfg["latent_tables"]:
+                cfg["ts"] = ts.detach().to(device=dev, dtype=torch.int64).contiguous()
+                if cfg["ts"].shape != (R,):
+                    raise ValueError(f"ts must be ({R},)")
+                a_emb = embeddings["a"].weight if need_a else None
+                t_emb = embeddings["t"].weight if need_t else None
             else:
+                if need_a:
+                    a_emb = kwargs["a_embedded"] if "a_embedded" in kwargs else embeddings["a"](ts)
+                    if tuple(a_emb.shape) != (R, f_f.desc.n_a):
+                        raise ValueError(f"a_embedded must be ({R}, {f_f.desc.n_a})")
+                if need_t:
+                    t_emb = kwargs["t_embedded"] if "t_embedded" in kwargs else embeddings["t"](ts)
+                    if tuple(t_emb.shape) != (R, f_f.desc.n_tau):
+                        raise ValueError(f"t_embedded must be ({R}, {f_f.desc.n_tau})")
+            if not cfg["use_t"]:            # the transient branch draws no density noise (rendering.py:146-149)
                 nf = kwargs.get("noise_fine")
                 nf = torch.randn(R, F, device=dev) if nf is None else _f32c(nf, "noise_fine", (R, F))
                 cfg["noise_f"] = nf if noise_std != 0 else None
