@@ -286,6 +286,16 @@ def run_rank(args):
         elapsed = float(t.item())
 
     n_ranks = dist.get_world_size() if dist is not None else 1
+    sync_diff = None
+    if dist is not None:
+        # data parallelism keeps the replicas identical: same seeded weights, the same averaged gradients, the same Adam.
+        # Largest difference between this rank's parameters and rank 0's, maximised over ranks: must be exactly 0.
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        d = (flat - ref).abs().max().reshape(1)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        sync_diff = float(d.item())
     F = N_SAMPLES + N_IMPORTANCE
     total_units = R * F * n_ranks * args.steps
     fine_kind = "at" if cfg3 else "base"
@@ -298,6 +308,7 @@ def run_rank(args):
         "unit": "ray-samples/s",
         "n_gpus": n_ranks,
         "ranks": n_ranks,
+        "replica_param_max_diff": sync_diff,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,

@@ -38,3 +38,21 @@ def test_refuses_a_process_group_of_another_size():
     assert p.returncode != 0
     assert "refusing" in p.stderr
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_ranks_drive_the_real_render_path():
+    """The N > 1 path with the REAL kernels: `python bench.py --gpus 2` starts two ranks that share the box's one GPU
+    (gloo for the collective, both on device 0: NFL_BENCH_BACKEND / NFL_BENCH_ONE_DEVICE), each renders and
+    back-propagates its own ray shard, the flat gradient all-reduce averages, Adam steps -- and the two replicas'
+    parameters stay bit-identical (the RCCL run itself needs the 8-GPU node)."""
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras"],
+             {"NFL_BENCH_BACKEND": "gloo", "NFL_BENCH_ONE_DEVICE": "1"}, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["ranks"] == 2
+    assert out["replica_param_max_diff"] == 0.0
+    assert out["value"] > 0
