@@ -8,7 +8,10 @@ from `oracle.nerfw_oracle.make_field_params(spec, seed, regime)` (numpy PCG64,
 platform independent) and pushed into the reference modules with
 load_state_dict(), so no reference source or checkpoint is stored here.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [prefix ...]   (e.g. g15_ g17_: only those cases)
+        PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py train            (w_trained.npz: the reference's own
+                                                                                        weights after 400 Adam steps;
+                                                                                        run it before the g17_* cases)
 """
 import json
 import os
