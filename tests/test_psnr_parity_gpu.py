@@ -83,8 +83,11 @@ def test_fit_psnr_matches_oracle():
 # 21.96 .. 22.11 dB (base; reference and replicas 21.88 .. 22.21) and 18.47 .. 18.52 dB (NeRF-W; 18.40 .. 18.44).
 # Training loss, windowed over 50 steps: the HIP-trained curve sits 3 .. 4 % BELOW the reference's on the base scene in
 # every launch (final window 0.00672 .. 0.00681 against 0.00701 .. 0.00715 for the three reference runs) and 0.3 .. 0.7 %
-# below on NeRF-W -- a small systematic offset of the mixed-precision backward whose cause is not established; it does
-# not show in validation PSNR.  The band on the windowed curves is 6 % (twice the reference's own 2 % plus that offset).
+# below on NeRF-W.  It is a late-phase effect: over the first 80 steps the HIP run tracks the reference curve to 2e-4
+# relative per 10-step window and 1e-6 per step (tests/report_psnr_curve.py), i.e. no bias of the mixed-precision
+# backward is visible before the trajectories decorrelate (which the reference's own replicas do at the same step,
+# by the same +-1..3 %); what differs afterwards is that the HIP gradients carry ~1e-3 of fresh rounding noise at every
+# step while a replica is perturbed once.  It does not show in validation PSNR.  The band on the windowed curves is 6 %.
 
 
 @pytest.mark.parametrize("kind", ["base", "nerfw"])
