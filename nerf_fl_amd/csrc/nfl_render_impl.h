@@ -44,6 +44,21 @@ template <> struct nfl_elem<b8> { using type = __bf16; };
 __device__ __forceinline__ f16v nfl_mfma(h8 a, h8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f16v nfl_mfma(b8 a, b8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 typedef float f4v __attribute__((ext_vector_type(4)));
+#ifdef NFL_ABL_MFMA16
+// TIMING ABLATION ONLY (results are wrong by construction): every 32x32x16 MFMA is issued as two 16x16x32 ones on
+// quarter Q and Q+1 of the same accumulator -- the same MFMA cycles, operand reads and register footprint as a
+// 16-row tiling of the kernel would have, under the kernel's real issue load
+template <int Q>
+__device__ __forceinline__ void nfl_mfma16x2(f16v& c, h8 a, h8 b) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int q = (Q + e) & 3;
+        f4v t = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, t, 0, 0, 0);
+        c[4 * q] = t[0]; c[4 * q + 1] = t[1]; c[4 * q + 2] = t[2]; c[4 * q + 3] = t[3];
+    }
+}
+#endif
 
 #define NFL_DEV __device__ __forceinline__
 // stash stores are streaming (nt): A/B on one box, training forward 1.69 ms with nt, 1.74 with plain stores (step 5.20 / 5.36 ms)
@@ -394,6 +409,19 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
         nfl_lds_wait<younger * NP, NP>(w[k % NW]);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
+#ifdef NFL_ABL_MFMA16
+            if (NP == 2) {
+                nfl_mfma16x2<(2 * k) & 3>(acc[cb], __builtin_bit_cast(V8, w[k % NW][NP - 1]), getb(K, cb, 0));
+                if (cb == 0) {
+                    if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                nfl_mfma16x2<(2 * k + 2) & 3>(acc[cb], __builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, NP - 1));
+                if (cb == 0) ring.template piece<P0 + k>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            nfl_mfma16x2<(2 * k) & 3>(acc[cb], __builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, 0));
+#else
             if (NP == 2) {
                 acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][NP - 1]), getb(K, cb, 0), acc[cb]);
                 if (cb == 0) {
@@ -405,6 +433,7 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, 0), acc[cb]);
+#endif
             if (NP == 1 && cb == 0) {
                 if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
                 ring.template piece<P0 + k>();
