@@ -50,6 +50,7 @@ segment (DESIGN.md section 3). Same-box A/B against the round-1 tree (both libra
 | `{tag}_summary.json` | the reduction (`traffic`: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB, the gfx950 correction of MI355X_MICROARCH.md; `sq.mfma_busy_frac`; `step_traffic`: bytes of one whole train step) — `bench.py` reads `roofline.traffic` and `step_traffic` from it |
 | `{tag}_time_passes.txt` | `tests/time_passes.py`: each kernel of the fine pass timed alone |
 | `{tag}_mfma_shape_probe2.txt` | `profiles/tools/mfma_shape_probe2.hip`: the `32x32x16` and `16x16x32` fp16 MFMA shapes under the issue load of the render kernel (LDS reads, LDS-DMA pieces, epilogue VALU, barrier): -15.5 % time bare, -10.5 % render-like — the basis of DESIGN.md section 9 |
+| `{tag}_mfma16_ablation.txt` | the real render kernel with every `32x32x16` MFMA issued as two `16x16x32` (`make variant VFLAGS=-DNFL_ABL_MFMA16`, timing only), alternated with the mainline on one box: inference forward 1.587 / 1.566 vs 1.529 / 1.523 ms (+3 %), training forward +0.7 % — the shape change does not pay in this kernel |
 | `tools/fp16_probe.hip`, `tools/trapsts_probe.hip` | what gfx950 does beyond fp16's range (cvt -> inf, `x - inf` -> -inf, MFMA `inf * 0` / `inf - inf` -> 0xFFC00000, relu on the bit pattern -> 0) and that the sticky exception bits stay clear: why the range check is explicit (DESIGN.md section 3) |
 
 Per launch, fine pass (4096 rays x 128 samples), this box:
