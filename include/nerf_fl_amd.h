@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NFL_ABI_VERSION 5
+#define NFL_ABI_VERSION 6
 #define NFL_GMAX_SLOTS 1024
 
 enum {
@@ -288,9 +288,17 @@ typedef struct nfl_field_grads {
  * transient on/off; the caller uploads it verbatim like the other plans). */
 size_t nfl_wgrad_plan_bytes(void);
 int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, void* h_plan, size_t bytes);
-/* d_gmax: the same 1024 floats the dgrad of this pass was given (the stashed gradients carry its loss scale) */
+/* d_gmax: the same 1024 floats the dgrad of this pass was given (the stashed gradients carry its loss scale).
+ * params / d_scratch: xyz_encoding_final is linear, so neither its output nor the gradient w.r.t. its output is ever
+ * stashed; the gradients of xyz_encoding_final and of the first 256 input columns of dir_encoding.0 /
+ * transient_encoding.0 are composed, in fp32, from G = sum_s delta_dirh (x) h8 (accumulated in d_scratch,
+ * nfl_wgrad_scratch_bytes() bytes, overwritten) and the CURRENT fp32 weights of those layers (`params`: the weights the
+ * forward pass ran with; weight[NFL_P_FINAL], bias[NFL_P_FINAL], weight[NFL_P_DIR] and, with the transient head,
+ * weight[NFL_P_T0] are read).  grads->bias[NFL_P_DIR] (and [NFL_P_T0]) must be given when any composed gradient is. */
+size_t nfl_wgrad_scratch_bytes(void);
 int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
-                  const float* d_gmax, int32_t n_rays, int32_t n_samples, const nfl_field_grads* grads, void* stream);
+                  const float* d_gmax, int32_t n_rays, int32_t n_samples, const nfl_field_params* params,
+                  float* d_scratch, const nfl_field_grads* grads, void* stream);
 
 /* ---- optimiser step (reference utils/__init__.py:30-32: torch.optim.Adam(lr, eps=1e-8), no weight decay, no
  * amsgrad) over up to NFL_ADAM_MAX_TENSORS fp32 tensors in one launch.  `step` is the 1-based count of this update

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFL_LIB") or os.path.join(_HERE, "libnerf_fl_amd.so")
 
-NFL_ABI_VERSION = 5
+NFL_ABI_VERSION = 6
 NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
@@ -137,8 +137,9 @@ SYMBOLS = [
     ("nfl_mlp_dgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DgradArgs), C.c_void_p]),
     ("nfl_wgrad_plan_bytes", C.c_size_t, []),
     ("nfl_wgrad_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),
+    ("nfl_wgrad_scratch_bytes", C.c_size_t, []),
     ("nfl_mlp_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                C.POINTER(FieldGrads), C.c_void_p]),
+                                C.POINTER(FieldParams), C.c_void_p, C.POINTER(FieldGrads), C.c_void_p]),
     ("nfl_adam_step", C.c_int, [C.POINTER(AdamTensors), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 C.c_void_p]),
     ("nfl_adam_step_dev", C.c_int, [C.POINTER(AdamTensors), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -88,14 +88,15 @@ struct NflPlan {
 #endif
 // ---- per-segment (32 samples) stash records, in k-steps of 1 KiB (64 lanes x 8 fp16) ----
 // forward activations (inputs of every layer), written by the training-mode forward:
-//   P | h1..h8 | feat | D (dir PE 2, appearance 3) | dirh | tau | g1..g4
+//   P | h1..h8 | D (dir PE 2, appearance 3) | dirh | tau | g1..g4
+// (no `feat`: xyz_encoding_final is linear and the gradients that would read its output are composed from
+//  sum_s delta_dirh (x) h8 instead, nfl_wgrad.hip)
 NFL_HD constexpr int nfl_act_h(int nkp, int l) { return nkp + 16 * (l - 1); }   // l = 1..8
-NFL_HD constexpr int nfl_act_feat(int nkp) { return nkp + 128; }
-NFL_HD constexpr int nfl_act_d(int nkp) { return nkp + 144; }
-NFL_HD constexpr int nfl_act_dirh(int nkp) { return nkp + 149; }
-NFL_HD constexpr int nfl_act_tau(int nkp) { return nkp + 157; }
-NFL_HD constexpr int nfl_act_g(int nkp, int m) { return nkp + 158 + 8 * (m - 1); }   // m = 1..4
-NFL_HD constexpr int nfl_act_slots(int nkp) { return nkp + 190; }
+NFL_HD constexpr int nfl_act_d(int nkp) { return nkp + 128; }
+NFL_HD constexpr int nfl_act_dirh(int nkp) { return nkp + 133; }
+NFL_HD constexpr int nfl_act_tau(int nkp) { return nkp + 141; }
+NFL_HD constexpr int nfl_act_g(int nkp, int m) { return nkp + 142 + 8 * (m - 1); }   // m = 1..4
+NFL_HD constexpr int nfl_act_slots(int nkp) { return nkp + 174; }
 // relu masks, written by the training-mode forward behind the activation records (one 32-bit word per lane and
 // row tile of a relu layer: bit 2p = value 2p of the lane's 16 accumulators was positive, bit 16+2p = value 2p+1;
 // 256 B per wave and tile instead of the 2 KiB of fp16 activations the dgrad kernel would otherwise re-read;
@@ -107,14 +108,13 @@ NFL_HD constexpr int nfl_msk_g(int m) { return 68 + 4 * (m - 1); }   // m = 1..4
 #define NFL_MSK_WORDS 84
 // byte offset of the mask records inside the activation stash buffer (after the records and their 4 KiB tail pad)
 NFL_HD constexpr size_t nfl_msk_offset(size_t n_seg, int nkp) { return n_seg * (size_t)nfl_act_slots(nkp) * 1024 + 4096; }
-// pre-activation gradients, written by the dgrad kernel:
-//   d1..d8 | dfeat | ddirh | dg1..dg4 | head grads as natural k-steps: dsigma, drgb, dsigma_t, drgb_t, dbeta
+// pre-activation gradients, written by the dgrad kernel (d(feat) lives in registers only, see above):
+//   d1..d8 | ddirh | dg1..dg4 | head grads as natural k-steps: dsigma, drgb, dsigma_t, drgb_t, dbeta
 #define NFL_GRD_D(l) (16 * ((l) - 1))
-#define NFL_GRD_FEAT 128
-#define NFL_GRD_DIRH 144
-#define NFL_GRD_G(m) (152 + 8 * ((m) - 1))
-#define NFL_GRD_HEADS 184
-#define NFL_GRD_SLOTS 189
+#define NFL_GRD_DIRH 128
+#define NFL_GRD_G(m) (136 + 8 * ((m) - 1))
+#define NFL_GRD_HEADS 168
+#define NFL_GRD_SLOTS 173
 
 #define NFL_GMAX_SLOTS 1024     // d_gmax is 1024 floats: workgroups spread their atomicMax over them, readers take the max
 // Loss scale of a backward pass: the power of two that brings max|head gradient| (bits of the fp32 the

@@ -876,7 +876,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         NFL_STAMP(9);
         K = nfl_kargs();           // head-side arguments (view directions, latents): loaded after the trunk
         if (!K->a.sigma_only) {
-            nfl_dense<NP, NCB, 16, 0, false, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_feat(NKP), mst, 0);   // final (linear)
+            // final (linear).  Never stashed: the weight gradients that would read it are composed from
+            // G = sum_s delta_dirh (x) h8 instead (nfl_wgrad.hip: "composed through xyz_encoding_final")
+            nfl_dense<NP, NCB, 16, 0, false, 8, 1, false>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, 0, mst, 0);
             NFL_STAMP(10);
             {
                 h8 D[5][NCB][NP];

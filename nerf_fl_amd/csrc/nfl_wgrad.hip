@@ -11,6 +11,16 @@
 // are DMA'd verbatim into LDS and read back with ds_read_b64_tr_b16 (hardware 4x16
 // transpose), two reads per MFMA operand, no extra pass over the data.
 //
+// Composed through xyz_encoding_final.  That layer is linear (feat = W_fin h8 + b_fin, no activation), and its
+// output is read by the direction layer and the first transient layer only, so
+//     delta_feat = Wd^T delta_dirh (+ Wt^T delta_g1)        Wd = W_dir[:, :256], Wt = W_t0[:, :256]
+// and with G = sum_s delta_dirh (x) h8  (128 x 256; Gt the same from delta_g1):
+//     dW_fin        = Wd^T G (+ Wt^T Gt)            db_fin = Wd^T db_dir (+ Wt^T db_t0)
+//     dW_dir[:, :256] = G W_fin^T + db_dir (x) b_fin    (dW_t0[:, :256] likewise from Gt)
+// Neither `feat` nor `delta_feat` is ever stashed (16 KiB per 32-sample segment less written by the forward, 16 less
+// by dgrad, 24 less read here); the stream accumulates G | Gt into a 256 x 256 scratch like any other job and
+// nfl_wgrad_compose_kernel finishes the four products in fp32 (34-67 MFLOP, one launch).
+//
 // Roofline: HBM.  A 256x256 layer reads 32 KiB per segment for 2 x 64 MFMAs, 128 FLOP/B,
 // far under the MFMA ridge, so the kernel is a stream (wg_body_rs below), with fp32 accumulators
 // for the whole (<=256 x <=352) tile of dW in registers and one fp32 atomic flush per workgroup.
@@ -37,8 +47,9 @@ struct WgTile {
     int16_t idx0;        // row0 / col0 of feature 0 of this tile in the weight
     int16_t nvalid;      // features of this tile that exist (<= 32)
 };
+#define WG_SCRATCH (-1)   // WgJob::layer of the job that accumulates G | Gt into WgArgs::scratch (256 x 256, ld 256)
 struct WgJob {
-    int32_t layer;       // NFL_P_* of the weight this job accumulates into
+    int32_t layer;       // NFL_P_* of the weight this job accumulates into, or WG_SCRATCH
     int32_t ld;          // row stride of that weight
     int32_t n_ot, n_it;
     int32_t n_wo, n_wi;  // waves across out tiles / in tiles (n_wo * n_wi == 4)
@@ -53,7 +64,7 @@ struct WgPlan {          // host-built once per (field, transient on/off); the c
     int32_t n_jobs;
     int32_t act_slots, grd_slots;
     int32_t w_numel[NFL_NUM_LAYERS], b_numel[NFL_NUM_LAYERS];   // sizes of the gradient tensors (0: layer absent)
-    int32_t cost[WG_MAX_JOBS];     // DMA pieces per wave per segment (4 / 5 / 8): the job's relative cost
+    int32_t cost[WG_MAX_JOBS];     // 1 KiB pieces per wave per segment (4 / 5 / 6 / 8): the job's relative cost
     WgJob job[WG_MAX_JOBS];
 };
 struct WgArgs {
@@ -63,6 +74,7 @@ struct WgArgs {
     int n_seg;
     int wg_start[WG_MAX_JOBS + 1];   // workgroups [wg_start[j], wg_start[j+1]) work on job j
     nfl_field_grads g;
+    float* scratch;      // (256, 256): rows 0..127 G (delta_dirh (x) h8), rows 128..255 Gt (delta_g1 (x) h8)
 };
 
 __device__ __forceinline__ int wg_orig(int kind, int i) {
@@ -113,7 +125,7 @@ __device__ __forceinline__ void wg_flush(const WgArgs& A, const WgJob& J, f16v (
         if (ot >= J.n_ot) continue;
         const WgTile TO = J.ot[ot];
         const int layer = J.bias_layer_of_ot[ot] >= 0 ? J.bias_layer_of_ot[ot] : J.layer;
-        float* W = A.g.weight[layer];
+        float* W = layer == WG_SCRATCH ? A.scratch : A.g.weight[layer];
         wg_static_for<0, NITW>([&](auto B) __attribute__((always_inline)) {
             constexpr int b = decltype(B)::value;
             if (wi + b * J.n_wi < J.n_it && W != nullptr) {
@@ -128,7 +140,7 @@ __device__ __forceinline__ void wg_flush(const WgArgs& A, const WgJob& J, f16v (
                 }
             }
         });
-        if (J.do_bias && wi == 0 && A.g.bias[layer] != nullptr) {
+        if (J.do_bias && wi == 0 && layer != WG_SCRATCH && A.g.bias[layer] != nullptr) {
             const float tot = bsum[a] + __shfl_xor(bsum[a], 32);
             const int oi = wg_orig(TO.kind, n);
             if (hh == 0 && oi < TO.nvalid) atomicAdd(A.g.bias[layer] + TO.idx0 + oi, tot);
@@ -144,11 +156,13 @@ __device__ __forceinline__ void wg_gload(wg_u4& dst, const char* ptr) {
 template <int N, int PW>
 __device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
     static_assert(N < 64, "vmcnt is a 6-bit counter");
-    static_assert(PW == 4 || PW == 5 || PW == 8, "piece counts the dispatcher uses");
+    static_assert(PW == 4 || PW == 5 || PW == 6 || PW == 8, "piece counts the dispatcher uses");
     if constexpr (PW == 4)
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
     else if constexpr (PW == 5)
         asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(N));
+    else if constexpr (PW == 6)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(N));
     else
         asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
                      "+v"(r[6]), "+v"(r[7]) : "n"(N));
@@ -279,6 +293,8 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
         else wg_body_rs<4, 2, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
     } else if (pw <= 5) {
         wg_body_rs<5, 2, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+    } else if (pw <= 6) {          // G of a pass without the transient head: 4 out x 8 in tiles
+        wg_body_rs<6, 4, 7>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
     } else {
         if (nitw <= 5) wg_body_rs<8, 5, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
         else if (nitw <= 6) wg_body_rs<8, 6, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
@@ -288,10 +304,85 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
 
 // Whole-tensor passes around the GEMM kernel: op 0 zeroes the gradient tensors, op 1 divides them by the loss
 // scale.  blockIdx.y = tensor (weights then biases), blockIdx.x strides over its elements.
+#define WG_NTENS (2 * NFL_NUM_LAYERS + 1)     // weights, biases, the composition scratch
 struct WgTensors {
-    float* ptr[2 * NFL_NUM_LAYERS];
-    int n[2 * NFL_NUM_LAYERS];
+    float* ptr[WG_NTENS];
+    int n[WG_NTENS];
 };
+
+// ---------------------------------------------------------------------------------
+// The four small fp32 products of the composition (file header), one launch: task t computes
+//   C[m, n] = sum_k A[m, k] B[k, n] (+ sum_k A2[m, k] B2[k, n]) (+ u[m] v[n])
+// over generic element strides, 32 x 32 output tiles per 256-thread workgroup, 32-wide k-steps through LDS.
+// The operands are the fp32 master weights and the finished (unscaled) G / bias gradients; everything is L2-resident.
+struct WgGemm {
+    const float* A; int sam, sak;
+    const float* B; int sbk, sbn;
+    const float* A2; int sam2, sak2;
+    const float* B2; int sbk2, sbn2;
+    const float* u; const float* v;       // rank-1 term (NULL: none)
+    float* Cp; int ldc;
+    int M, N, K, K2;                      // K2 = 0: no second product
+    int tiles_n, tile0;                   // tiles across N; index of this task's first workgroup
+};
+#define WG_MAX_GEMM 4
+struct WgCompose {
+    int n_tasks, n_wg;
+    WgGemm t[WG_MAX_GEMM];
+};
+__global__ __launch_bounds__(256) void nfl_wgrad_compose_kernel(const WgCompose Cc) {
+    __shared__ float sa[32][33], sb[32][33];
+    int ti = 0;
+    while (ti + 1 < Cc.n_tasks && (int)blockIdx.x >= Cc.t[ti + 1].tile0) ++ti;
+    const WgGemm& T = Cc.t[ti];
+    const int tile = blockIdx.x - T.tile0, m0 = 32 * (tile / T.tiles_n), n0 = 32 * (tile % T.tiles_n);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // thread: column tx, rows ty, ty+8, ty+16, ty+24
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* A = pass ? T.A2 : T.A;
+        const float* B = pass ? T.B2 : T.B;
+        const int Kp = pass ? T.K2 : T.K;
+        const int sam = pass ? T.sam2 : T.sam, sak = pass ? T.sak2 : T.sak, sbk = pass ? T.sbk2 : T.sbk, sbn = pass ? T.sbn2 : T.sbn;
+        for (int k0 = 0; k0 < Kp; k0 += 32) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = ty + 8 * r;
+                // the faster-varying index of each operand in memory rides on tx
+                if (sak <= sam) {
+                    const int m = m0 + row, k = k0 + tx;
+                    sa[row][tx] = (m < T.M && k < Kp) ? A[(size_t)m * sam + (size_t)k * sak] : 0.f;
+                } else {
+                    const int m = m0 + tx, k = k0 + row;
+                    sa[tx][row] = (m < T.M && k < Kp) ? A[(size_t)m * sam + (size_t)k * sak] : 0.f;
+                }
+                if (sbn <= sbk) {
+                    const int k = k0 + row, n = n0 + tx;
+                    sb[row][tx] = (k < Kp && n < T.N) ? B[(size_t)k * sbk + (size_t)n * sbn] : 0.f;
+                } else {
+                    const int k = k0 + tx, n = n0 + row;
+                    sb[tx][row] = (k < Kp && n < T.N) ? B[(size_t)k * sbk + (size_t)n * sbn] : 0.f;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const float b = sb[k][tx];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(sa[ty + 8 * r][k], b, acc[r]);
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + ty + 8 * r, n = n0 + tx;
+        if (m < T.M && n < T.N) {
+            float c = acc[r];
+            if (T.u) c = __builtin_fmaf(T.u[m], T.v[n], c);
+            T.Cp[(size_t)m * T.ldc + n] = c;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void nfl_wgrad_scale_kernel(const WgTensors T, const int op, const float* gmax) {
     float* p = T.ptr[blockIdx.y];
     const int n = T.n[blockIdx.y];
@@ -357,7 +448,8 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
     auto push = [&](WgJob j) {
         finish_job(j);
         const int pw = (2 * (j.n_ot + j.n_it) + 3) / 4;
-        P.cost[nj] = pw <= 4 ? 4 : (pw <= 5 ? 5 : 8);
+        const int nitw = (j.n_it + j.n_wi - 1) / j.n_wi;
+        P.cost[nj] = pw <= 4 ? 4 : (pw <= 5 ? 5 : ((pw <= 6 && nitw <= 4) ? 6 : 8));
         P.job[nj++] = j;
     };
     for (int l = 1; l <= 8; ++l) {
@@ -382,16 +474,17 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
         add_tiles(j.it, j.n_it, nfl_act_h(nkp, 8), NFL_SEG_ACT, 0, W);
         push(j);
     }
-    {   // xyz_encoding_final
-        WgJob j = make_job(NFL_P_FINAL, W, true);
-        add_tiles(j.ot, j.n_ot, NFL_GRD_FEAT, NFL_SEG_ACT, 0, W);
+    {   // G | Gt = (delta_dirh | delta_g1) (x) h8 into the scratch: everything that touches `feat` (xyz_encoding_final
+        // itself and the first 256 input columns of dir_encoding / transient_encoding.0) is composed from it
+        WgJob j = make_job(WG_SCRATCH, W, false);
+        add_tiles(j.ot, j.n_ot, NFL_GRD_DIRH, NFL_SEG_ACT, 0, H);
+        if (ut) add_tiles(j.ot, j.n_ot, NFL_GRD_G(1), NFL_SEG_ACT, H, H);
         add_tiles(j.it, j.n_it, nfl_act_h(nkp, 8), NFL_SEG_ACT, 0, W);
         push(j);
     }
-    {   // dir_encoding: inputs [feat | dir PE | appearance]
+    {   // dir_encoding: the side inputs [dir PE | appearance] (columns 256..) and the bias
         WgJob j = make_job(NFL_P_DIR, p.ld[NFL_P_DIR], true);
         add_tiles(j.ot, j.n_ot, NFL_GRD_DIRH, NFL_SEG_ACT, 0, H);
-        add_tiles(j.it, j.n_it, nfl_act_feat(nkp), NFL_SEG_ACT, 0, W);
         add_tiles(j.it, j.n_it, nfl_act_d(nkp), NFL_SEG_NAT, W, 27);
         if (p.has_a) add_tiles(j.it, j.n_it, nfl_act_d(nkp) + 2, NFL_SEG_NAT, W + 27, p.n_a);
         push(j);
@@ -406,8 +499,7 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
         {
             WgJob j = make_job(NFL_P_T0, p.ld[NFL_P_T0], true);
             add_tiles(j.ot, j.n_ot, NFL_GRD_G(1), NFL_SEG_ACT, 0, H);
-            add_tiles(j.it, j.n_it, nfl_act_feat(nkp), NFL_SEG_ACT, 0, W);
-            add_tiles(j.it, j.n_it, nfl_act_tau(nkp), NFL_SEG_NAT, W, d->n_tau);
+            add_tiles(j.it, j.n_it, nfl_act_tau(nkp), NFL_SEG_NAT, W, d->n_tau);      // the transient code (columns 256..) and the bias
             push(j);
         }
         for (int m = 2; m <= 4; ++m) {
@@ -440,12 +532,22 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
     return NFL_OK;
 }
 
+extern "C" size_t nfl_wgrad_scratch_bytes(void) { return (size_t)NFL_W * NFL_W * sizeof(float); }
+
 extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash,
                              const char* d_grad_stash, const float* d_gmax, int32_t n_rays, int32_t n_samples,
-                             const nfl_field_grads* grads, void* stream) {
+                             const nfl_field_params* params, float* d_scratch, const nfl_field_grads* grads,
+                             void* stream) {
     const WgPlan* hp = static_cast<const WgPlan*>(h_wplan);
-    if (!hp || hp->magic != (NFL_PLAN_MAGIC ^ 0x57u) || !d_wplan || !d_act_stash || !d_grad_stash || !d_gmax || !grads)
+    if (!hp || hp->magic != (NFL_PLAN_MAGIC ^ 0x57u) || !d_wplan || !d_act_stash || !d_grad_stash || !d_gmax || !grads
+        || !params || !d_scratch)
         return NFL_EINVAL;
+    // the composition reads these master weights; the side-input job of a layer needs its bias gradient as well
+    if (!params->weight[NFL_P_FINAL] || !params->bias[NFL_P_FINAL] || !params->weight[NFL_P_DIR]) return NFL_EINVAL;
+    const bool ut = hp->n_jobs > 0 && hp->job[hp->n_jobs - 1].layer == NFL_P_TSIGMA;
+    if (ut && !params->weight[NFL_P_T0]) return NFL_EINVAL;
+    if ((grads->weight[NFL_P_DIR] || grads->weight[NFL_P_FINAL]) && !grads->bias[NFL_P_DIR]) return NFL_EINVAL;
+    if (ut && (grads->weight[NFL_P_T0] || grads->weight[NFL_P_FINAL]) && !grads->bias[NFL_P_T0]) return NFL_EINVAL;
     if (n_rays < 0 || n_samples < 1) return NFL_EINVAL;
     WgArgs A;
     memset(&A, 0, sizeof(A));
@@ -454,6 +556,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     A.grd = d_grad_stash;
     A.n_seg = n_rays * ((n_samples + 31) / 32);
     A.g = *grads;
+    A.scratch = d_scratch;
     // one workgroup per CU, dealt to the jobs in proportion to their streamed bytes
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -500,10 +603,59 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
         T.ptr[NFL_NUM_LAYERS + L] = grads->bias[L];
         T.n[NFL_NUM_LAYERS + L] = hp->b_numel[L];
     }
+    T.ptr[2 * NFL_NUM_LAYERS] = d_scratch;
+    T.n[2 * NFL_NUM_LAYERS] = NFL_W * NFL_W;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, 2 * NFL_NUM_LAYERS), dim3(256), 0, s, T, 0, d_gmax);
+    hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 0, d_gmax);
     if (n_rays == 0) return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
     hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, A);
-    hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, 2 * NFL_NUM_LAYERS), dim3(256), 0, s, T, 1, d_gmax);
+    hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 1, d_gmax);
+
+    // the composition through xyz_encoding_final (file header); G, db_dir, db_t0 are final (unscaled) by now
+    const int W = NFL_W, H = NFL_W / 2;
+    const int ld_dir = hp->w_numel[NFL_P_DIR] / H, ld_t0 = ut ? hp->w_numel[NFL_P_T0] / H : 0;
+    const float* Wd = params->weight[NFL_P_DIR];
+    const float* Wt = ut ? params->weight[NFL_P_T0] : nullptr;
+    const float* Wf = params->weight[NFL_P_FINAL];
+    const float* G = d_scratch;
+    const float* Gt = d_scratch + (size_t)H * W;
+    WgCompose Cc;
+    memset(&Cc, 0, sizeof(Cc));
+    auto add = [&](WgGemm g) {
+        g.tiles_n = (g.N + 31) / 32;
+        g.tile0 = Cc.n_wg;
+        Cc.n_wg += g.tiles_n * ((g.M + 31) / 32);
+        Cc.t[Cc.n_tasks++] = g;
+    };
+    WgGemm g;
+    if (grads->weight[NFL_P_FINAL]) {       // dW_fin[i, j] = sum_r Wd[r, i] G[r, j] (+ sum_r Wt[r, i] Gt[r, j])
+        memset(&g, 0, sizeof(g));
+        g.A = Wd; g.sam = 1; g.sak = ld_dir; g.B = G; g.sbk = W; g.sbn = 1; g.K = H;
+        if (ut) { g.A2 = Wt; g.sam2 = 1; g.sak2 = ld_t0; g.B2 = Gt; g.sbk2 = W; g.sbn2 = 1; g.K2 = H; }
+        g.Cp = grads->weight[NFL_P_FINAL]; g.ldc = W; g.M = W; g.N = W;
+        add(g);
+    }
+    if (grads->bias[NFL_P_FINAL]) {         // db_fin[i] = sum_r Wd[r, i] db_dir[r] (+ sum_r Wt[r, i] db_t0[r]): a 256 x 1 product
+        memset(&g, 0, sizeof(g));
+        g.A = Wd; g.sam = 1; g.sak = ld_dir; g.B = grads->bias[NFL_P_DIR]; g.sbk = 1; g.sbn = 1; g.K = H;
+        if (ut) { g.A2 = Wt; g.sam2 = 1; g.sak2 = ld_t0; g.B2 = grads->bias[NFL_P_T0]; g.sbk2 = 1; g.sbn2 = 1; g.K2 = H; }
+        g.Cp = grads->bias[NFL_P_FINAL]; g.ldc = 1; g.M = W; g.N = 1;
+        add(g);
+    }
+    if (grads->weight[NFL_P_DIR]) {         // dW_dir[r, i] = sum_j G[r, j] W_fin[i, j] + db_dir[r] b_fin[i], i < 256
+        memset(&g, 0, sizeof(g));
+        g.A = G; g.sam = W; g.sak = 1; g.B = Wf; g.sbk = 1; g.sbn = W; g.K = W;
+        g.u = grads->bias[NFL_P_DIR]; g.v = params->bias[NFL_P_FINAL];
+        g.Cp = grads->weight[NFL_P_DIR]; g.ldc = ld_dir; g.M = H; g.N = W;
+        add(g);
+    }
+    if (ut && grads->weight[NFL_P_T0]) {
+        memset(&g, 0, sizeof(g));
+        g.A = Gt; g.sam = W; g.sak = 1; g.B = Wf; g.sbk = 1; g.sbn = W; g.K = W;
+        g.u = grads->bias[NFL_P_T0]; g.v = params->bias[NFL_P_FINAL];
+        g.Cp = grads->weight[NFL_P_T0]; g.ldc = ld_t0; g.M = H; g.N = W;
+        add(g);
+    }
+    if (Cc.n_wg > 0) hipLaunchKernelGGL(nfl_wgrad_compose_kernel, dim3(Cc.n_wg), dim3(256), 0, s, Cc);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

@@ -493,7 +493,9 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     _lib.check(L.nfl_mlp_dgrad(bp["h"], _ptr(bp["d"]), _ptr(bp["packed"]), C.byref(da), _stream()), "nfl_mlp_dgrad")
 
     plist = field.param_list()
-    arena = torch.empty(sum(w.numel() + b.numel() for _, w, b in plist), dtype=torch.float32, device=dev)   # zeroed by the call
+    n_par = sum(w.numel() + b.numel() for _, w, b in plist)
+    n_scr = L.nfl_wgrad_scratch_bytes() // 4       # composition scratch (G: include/nerf_fl_amd.h, nfl_mlp_wgrad), behind the gradients
+    arena = torch.empty(n_par + n_scr, dtype=torch.float32, device=dev)   # zeroed by the call
     fg = _lib.FieldGrads()
     views, off = [], 0
     for i, w, b in plist:
@@ -504,8 +506,9 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
         fg.weight[i], fg.bias[i] = gw.data_ptr(), gb.data_ptr()
         views += [gw, gb]
     h_wp, d_wp = field.wgrad_plan(use_t)
-    _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), _ptr(gmax), R, N, C.byref(fg),
-                               _stream()),
+    fp, _keep = field._field_params()          # the fp32 weights the forward ran with (read by the composition)
+    _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), _ptr(gmax), R, N, C.byref(fp),
+                               C.c_void_p(arena.data_ptr() + 4 * n_par), C.byref(fg), _stream()),
                "nfl_mlp_wgrad")
     return views, g_a, g_t
 

@@ -87,9 +87,9 @@ def test_bwd_plan_structure(L):
     assert L.nfl_bwd_plan_build(C.byref(d), 1, buf, n) == 0
     hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)
     assert hdr2[5] == 1 and hdr2[12] == n_rt + 5 and hdr2[15] == n_chunks + 5 and hdr2[18] == total_ks + 8 + 4 * 16
-    # stash sizes: per 32-sample segment 194 / 189 KiB (+ 4 KiB tail pad), then 84 relu-mask words x 256 B per segment
-    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 194 * 1024 + 4096 + 8 * 4 * 84 * 256
-    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == (8 * 4 + 1) * 189 * 1024 + 4096
+    # stash sizes: per 32-sample segment 178 / 173 KiB (no slot for xyz_encoding_final's output or its gradient: composed) (+ 4 KiB tail pad), then 84 relu-mask words x 256 B per segment
+    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 178 * 1024 + 4096 + 8 * 4 * 84 * 256
+    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == (8 * 4 + 1) * 173 * 1024 + 4096
 
 
 def test_unsupported_configs_rejected(L):
@@ -132,7 +132,8 @@ def test_auxiliary_entry_points_validate_arguments(L):
     assert L.nfl_field_forward(None, None, None, None, 4, 90, 0, 0, None, None) == -1
     assert L.nfl_posenc(None, 4, 10, None, None, None) == -1
     assert L.nfl_composite_backward(None, None) == -1 and L.nfl_mlp_dgrad(None, None, None, None, None) == -1
-    assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, None, None) == -1
+    assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, None, None, None, None) == -1
+    assert L.nfl_wgrad_scratch_bytes() == 256 * 256 * 4
 
 
 def test_adam_step_dev_validates_arguments(L):

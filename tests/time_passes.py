@@ -73,5 +73,7 @@ if prec == "f16x3":
         fg.weight[i] = arena[off:off + w.numel()].data_ptr(); off += w.numel()
         fg.bias[i] = arena[off:off + b.numel()].data_ptr(); off += b.numel()
     h_wp, d_wp = f.wgrad_plan(False)
-    print("wgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_wgrad(h_wp, rnd._ptr(d_wp), rnd._ptr(st["act"]), rnd._ptr(grad_stash), rnd._ptr(gmax), R, F, C.byref(fg), rnd._stream()), "wg")))
+    fpar, _keep = f._field_params()
+    scratch = torch.empty(L.nfl_wgrad_scratch_bytes() // 4, device=dev)
+    print("wgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_wgrad(h_wp, rnd._ptr(d_wp), rnd._ptr(st["act"]), rnd._ptr(grad_stash), rnd._ptr(gmax), R, F, C.byref(fpar), rnd._ptr(scratch), C.byref(fg), rnd._stream()), "wg")))
     print("act stash %.2f GB, grad stash %.2f GB" % (st["act"].numel() / 1e9, grad_stash.numel() / 1e9))
