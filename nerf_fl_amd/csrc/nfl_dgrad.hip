@@ -489,9 +489,11 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             nfl_split8<1>(vTb, dTb[0][cb]);
             nfl_stash8(vS, gst[cb] + (NFL_GRD_HEADS + 0) * 1024);
             nfl_stash8(vC, gst[cb] + (NFL_GRD_HEADS + 1) * 1024);
-            nfl_stash8(vTs, gst[cb] + (NFL_GRD_HEADS + 2) * 1024);
-            nfl_stash8(vTc, gst[cb] + (NFL_GRD_HEADS + 3) * 1024);
-            nfl_stash8(vTb, gst[cb] + (NFL_GRD_HEADS + 4) * 1024);
+            if (K->use_t) {        // no weight-gradient job reads them otherwise
+                nfl_stash8(vTs, gst[cb] + (NFL_GRD_HEADS + 2) * 1024);
+                nfl_stash8(vTc, gst[cb] + (NFL_GRD_HEADS + 3) * 1024);
+                nfl_stash8(vTb, gst[cb] + (NFL_GRD_HEADS + 4) * 1024);
+            }
         }
         // Two operand sets of 16 k-steps are enough for the whole walk: the transient chain ping-pongs between
         // the halves of Q, d(dir hidden) lands in Q[0..8) next to dg1 in Q[8..16), d(feat) in P, then the trunk

@@ -54,7 +54,7 @@ struct WgJob {
     int32_t n_ot, n_it;
     int32_t n_wo, n_wi;  // waves across out tiles / in tiles (n_wo * n_wi == 4)
     int32_t do_bias;
-    int32_t bias_layer_of_ot[WG_MAX_OT];   // heads: each out tile may belong to another layer (-1: use `layer`)
+    int32_t bias_layer_of_ot[WG_MAX_OT];   // each out tile may belong to another layer, weight and bias (-1: use `layer`)
     WgTile ot[WG_MAX_OT];
     WgTile it[WG_MAX_IT];
 };
@@ -468,17 +468,23 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
         }
         push(j);
     }
-    {   // sigma head
+    if (ut) {   // sigma head (without the transient head it shares the h8 stream of the next job)
         WgJob j = make_job(NFL_P_SIGMA, W, true);
         add_tiles(j.ot, j.n_ot, NFL_GRD_HEADS + 0, NFL_SEG_NAT, 0, 1);
         add_tiles(j.it, j.n_it, nfl_act_h(nkp, 8), NFL_SEG_ACT, 0, W);
         push(j);
     }
     {   // G | Gt = (delta_dirh | delta_g1) (x) h8 into the scratch: everything that touches `feat` (xyz_encoding_final
-        // itself and the first 256 input columns of dir_encoding / transient_encoding.0) is composed from it
-        WgJob j = make_job(WG_SCRATCH, W, false);
+        // itself and the first 256 input columns of dir_encoding / transient_encoding.0) is composed from it.
+        // Without the transient head there is room for a fifth out tile: the sigma head reads the same h8 (ld 256 too)
+        WgJob j = make_job(WG_SCRATCH, W, !ut);
         add_tiles(j.ot, j.n_ot, NFL_GRD_DIRH, NFL_SEG_ACT, 0, H);
-        if (ut) add_tiles(j.ot, j.n_ot, NFL_GRD_G(1), NFL_SEG_ACT, H, H);
+        if (ut) {
+            add_tiles(j.ot, j.n_ot, NFL_GRD_G(1), NFL_SEG_ACT, H, H);
+        } else {
+            j.bias_layer_of_ot[j.n_ot] = NFL_P_SIGMA;
+            add_tiles(j.ot, j.n_ot, NFL_GRD_HEADS + 0, NFL_SEG_NAT, 0, 1);
+        }
         add_tiles(j.it, j.n_it, nfl_act_h(nkp, 8), NFL_SEG_ACT, 0, W);
         push(j);
     }
