@@ -313,7 +313,7 @@ struct WgTensors {
 // ---------------------------------------------------------------------------------
 // The four small fp32 products of the composition (file header), one launch: task t computes
 //   C[m, n] = sum_k A[m, k] B[k, n] (+ sum_k A2[m, k] B2[k, n]) (+ u[m] v[n])
-// over generic element strides, 32 x 32 output tiles per 256-thread workgroup, 32-wide k-steps through LDS.
+// over element strides of which one per operand is 1, 32 x 32 output tiles per 256-thread workgroup.
 // The operands are the fp32 master weights and the finished (unscaled) G / bias gradients; everything is L2-resident.
 struct WgGemm {
     const float* A; int sam, sak;
@@ -330,57 +330,68 @@ struct WgCompose {
     int n_tasks, n_wg;
     WgGemm t[WG_MAX_GEMM];
 };
+// One 32 x 32 output tile per workgroup on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact products, fp32
+// accumulation): the four waves split K, every lane fetches its operands straight from global memory (float4 along k where
+// k is the contiguous index, one dword per k otherwise; all loads of a wave are in flight before its first MFMA), the
+// partial tiles meet in LDS.  MFMA j of a wave takes, in lane half h, k = k_wave + 8 (j / 4) + 4 h + (j % 4): any pairing
+// of the two k of a step is as good as another as long as A and B agree.  (The first version staged 32 x 128 operand
+// blocks through LDS for scalar FMAs and was LDS-bound: 20-30 us; this one is one memory round trip and 16-32 MFMAs per wave.)
+typedef float wg_f4 __attribute__((ext_vector_type(4)));
+template <int NJ>       // MFMAs per wave = (K / 4) / 2
+__device__ __forceinline__ void wg_compose_pass(f16v& acc, const float* A, int sam, int sak, const float* B, int sbk, int sbn,
+                                                int m, int n, bool n_ok, int k_wave, int h) {
+    float ra[NJ], rb[NJ];
+#pragma unroll
+    for (int g = 0; g < NJ / 4; ++g) {
+        const int kq = k_wave + 8 * g + 4 * h;
+        if (sak == 1) {
+            const wg_f4 v = *reinterpret_cast<const wg_f4*>(A + (size_t)m * sam + kq);
+            ra[4 * g] = v[0]; ra[4 * g + 1] = v[1]; ra[4 * g + 2] = v[2]; ra[4 * g + 3] = v[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ra[4 * g + e] = A[(size_t)m * sam + (size_t)(kq + e) * sak];
+        }
+        if (!n_ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[4 * g + e] = 0.f;
+        } else if (sbk == 1 && sbn != 1) {
+            const wg_f4 v = *reinterpret_cast<const wg_f4*>(B + (size_t)n * sbn + kq);
+            rb[4 * g] = v[0]; rb[4 * g + 1] = v[1]; rb[4 * g + 2] = v[2]; rb[4 * g + 3] = v[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) rb[4 * g + e] = B[(size_t)(kq + e) * sbk + (size_t)n * sbn];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[j], rb[j], acc, 0, 0, 0);
+}
+
 __global__ __launch_bounds__(256) void nfl_wgrad_compose_kernel(const WgCompose Cc) {
-    __shared__ float sa[32][33], sb[32][33];
+    __shared__ float red[4][16][64];
     int ti = 0;
     while (ti + 1 < Cc.n_tasks && (int)blockIdx.x >= Cc.t[ti + 1].tile0) ++ti;
     const WgGemm& T = Cc.t[ti];
     const int tile = blockIdx.x - T.tile0, m0 = 32 * (tile / T.tiles_n), n0 = 32 * (tile % T.tiles_n);
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // thread: column tx, rows ty, ty+8, ty+16, ty+24
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int pass = 0; pass < 2; ++pass) {
-        const float* A = pass ? T.A2 : T.A;
-        const float* B = pass ? T.B2 : T.B;
-        const int Kp = pass ? T.K2 : T.K;
-        const int sam = pass ? T.sam2 : T.sam, sak = pass ? T.sak2 : T.sak, sbk = pass ? T.sbk2 : T.sbk, sbn = pass ? T.sbn2 : T.sbn;
-        for (int k0 = 0; k0 < Kp; k0 += 32) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+    const int m = m0 + (lane & 31), n = n0 + (lane & 31);      // M is a multiple of 32 (256 or 128); N is 256 or 1
+    const bool n_ok = n < T.N;
+    f16v acc;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = ty + 8 * r;
-                // the faster-varying index of each operand in memory rides on tx
-                if (sak <= sam) {
-                    const int m = m0 + row, k = k0 + tx;
-                    sa[row][tx] = (m < T.M && k < Kp) ? A[(size_t)m * sam + (size_t)k * sak] : 0.f;
-                } else {
-                    const int m = m0 + tx, k = k0 + row;
-                    sa[tx][row] = (m < T.M && k < Kp) ? A[(size_t)m * sam + (size_t)k * sak] : 0.f;
-                }
-                if (sbn <= sbk) {
-                    const int k = k0 + row, n = n0 + tx;
-                    sb[row][tx] = (k < Kp && n < T.N) ? B[(size_t)k * sbk + (size_t)n * sbn] : 0.f;
-                } else {
-                    const int k = k0 + tx, n = n0 + row;
-                    sb[tx][row] = (k < Kp && n < T.N) ? B[(size_t)k * sbk + (size_t)n * sbn] : 0.f;
-                }
-            }
-            __syncthreads();
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // K and K2 are 128 or 256 (host-checked): 32 or 64 per wave
+    if (T.K == 256) wg_compose_pass<32>(acc, T.A, T.sam, T.sak, T.B, T.sbk, T.sbn, m, n, n_ok, 64 * wave, h);
+    else wg_compose_pass<16>(acc, T.A, T.sam, T.sak, T.B, T.sbk, T.sbn, m, n, n_ok, 32 * wave, h);
+    if (T.K2 == 256) wg_compose_pass<32>(acc, T.A2, T.sam2, T.sak2, T.B2, T.sbk2, T.sbn2, m, n, n_ok, 64 * wave, h);
+    else if (T.K2 == 128) wg_compose_pass<16>(acc, T.A2, T.sam2, T.sak2, T.B2, T.sbk2, T.sbn2, m, n, n_ok, 32 * wave, h);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) {
-                const float b = sb[k][tx];
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(sa[ty + 8 * r][k], b, acc[r]);
-            }
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + ty + 8 * r, n = n0 + tx;
-        if (m < T.M && n < T.N) {
-            float c = acc[r];
-            if (T.u) c = __builtin_fmaf(T.u[m], T.v[n], c);
-            T.Cp[(size_t)m * T.ldc + n] = c;
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int r = 4 * wave + q;                             // accumulator register r: row 8 (r / 4) + 4 h + (r % 4), column lane % 32
+        const float c = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
+        const int row = m0 + 8 * (r >> 2) + 4 * h + (r & 3);
+        if (n_ok) T.Cp[(size_t)row * T.ldc + n] = T.u ? __builtin_fmaf(T.u[row], T.v[n], c) : c;
     }
 }
 __global__ __launch_bounds__(256) void nfl_wgrad_scale_kernel(const WgTensors T, const int op, const float* gmax) {
@@ -662,6 +673,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
         g.Cp = grads->weight[NFL_P_T0]; g.ldc = ld_t0; g.M = H; g.N = W;
         add(g);
     }
+    if (((uintptr_t)d_scratch | (uintptr_t)Wf) & 15) return NFL_EINVAL;      // float4 loads along k (G, W_fin rows)
     if (Cc.n_wg > 0) hipLaunchKernelGGL(nfl_wgrad_compose_kernel, dim3(Cc.n_wg), dim3(256), 0, s, Cc);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

@@ -495,9 +495,9 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     plist = field.param_list()
     n_par = sum(w.numel() + b.numel() for _, w, b in plist)
     n_scr = L.nfl_wgrad_scratch_bytes() // 4       # composition scratch (G: include/nerf_fl_amd.h, nfl_mlp_wgrad), behind the gradients
-    arena = torch.empty(n_par + n_scr, dtype=torch.float32, device=dev)   # zeroed by the call
+    arena = torch.empty(n_scr + n_par, dtype=torch.float32, device=dev)   # zeroed by the call; scratch first (16-byte aligned)
     fg = _lib.FieldGrads()
-    views, off = [], 0
+    views, off = [], n_scr
     for i, w, b in plist:
         gw = arena[off:off + w.numel()].view_as(w)
         off += w.numel()
@@ -508,7 +508,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     h_wp, d_wp = field.wgrad_plan(use_t)
     fp, _keep = field._field_params()          # the fp32 weights the forward ran with (read by the composition)
     _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), _ptr(gmax), R, N, C.byref(fp),
-                               C.c_void_p(arena.data_ptr() + 4 * n_par), C.byref(fg), _stream()),
+                               C.c_void_p(arena.data_ptr()), C.byref(fg), _stream()),
                "nfl_mlp_wgrad")
     return views, g_a, g_t
 
