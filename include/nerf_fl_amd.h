@@ -100,6 +100,18 @@ size_t nfl_param_count(const nfl_field_desc* desc);
  * when a weight does not fit fp16's range. */
 int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_params* params,
                    void* d_packed, size_t packed_bytes, int32_t* d_status, void* stream);
+/* Several streams in one launch (a training step re-packs the forward and the dgrad stream of both fields after every
+ * optimizer update).  Same argument meaning and checks as nfl_pack_field, per job. */
+#define NFL_PACK_MAX_JOBS 4
+typedef struct nfl_pack_job {
+    const void* h_plan;
+    const void* d_plan;
+    const nfl_field_params* params;
+    void* d_packed;
+    size_t packed_bytes;
+    int32_t* d_status;          /* may be NULL */
+} nfl_pack_job;
+int nfl_pack_fields(int32_t n_jobs, const nfl_pack_job* jobs, void* stream);
 
 /* ---- one rendering pass (reference: inference(), rendering.py:83-226) --- */
 

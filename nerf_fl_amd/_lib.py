@@ -40,6 +40,14 @@ class FieldParams(C.Structure):
     _fields_ = [("weight", C.c_void_p * NFL_NUM_LAYERS), ("bias", C.c_void_p * NFL_NUM_LAYERS)]
 
 
+class PackJob(C.Structure):
+    _fields_ = [("h_plan", C.c_void_p), ("d_plan", C.c_void_p), ("params", C.POINTER(FieldParams)), ("d_packed", C.c_void_p),
+                ("packed_bytes", C.c_size_t), ("d_status", C.c_void_p)]
+
+
+NFL_PACK_MAX_JOBS = 4
+
+
 class Camera(C.Structure):
     _fields_ = [("c2w", C.c_float * 12), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
                 ("width", C.c_int32), ("reserved", C.c_int32), ("pix0", C.c_int64), ("near", C.c_float), ("far", C.c_float)]
@@ -121,6 +129,7 @@ SYMBOLS = [
     ("nfl_param_count", C.c_size_t, [C.POINTER(FieldDesc)]),
     ("nfl_pack_field", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FieldParams), C.c_void_p, C.c_size_t, C.c_void_p,
                                  C.c_void_p]),
+    ("nfl_pack_fields", C.c_int, [C.c_int32, C.POINTER(PackJob), C.c_void_p]),
     ("nfl_render_pass", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassArgs), C.c_void_p]),
     ("nfl_sample_pdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),

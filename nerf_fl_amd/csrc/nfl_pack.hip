@@ -22,10 +22,21 @@ struct PackArgs {
     int32_t* status;            // NFL_STATUS_RANGE is OR-ed in when a weight exceeds fp16's range; may be null
 };
 
-__global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
+// up to NFL_PACK_MAX_JOBS streams in one launch (a training step re-packs the forward and the dgrad stream of both
+// fields after every optimizer update: four 8 us launches of pure latency became one)
+struct PackBatch {
+    int n;
+    int first_block[NFL_PACK_MAX_JOBS + 1];
+    PackArgs job[NFL_PACK_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(64) void nfl_pack_kernel(const PackBatch B) {
+    int jb = 0;
+    while (jb + 1 < B.n && (int)blockIdx.x >= B.first_block[jb + 1]) ++jb;
+    const PackArgs& a = B.job[jb];
     const NflPlan& P = *a.plan;
     const int lane = threadIdx.x;
-    const int gks = blockIdx.x;          // global k-step index in the stream
+    const int gks = blockIdx.x - B.first_block[jb];          // global k-step index in the stream
     if (gks >= P.total_ks) {
         // bias table: blocks total_ks .. total_ks + n_rt - 1, lanes 0..31
         const int t = gks - P.total_ks;
@@ -111,17 +122,37 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(PackArgs a) {
     }
 }
 
+extern "C" int nfl_pack_fields(int32_t n_jobs, const nfl_pack_job* jobs, void* stream) {
+    if (n_jobs < 0 || n_jobs > NFL_PACK_MAX_JOBS || (n_jobs > 0 && !jobs)) return NFL_EINVAL;
+    if (n_jobs == 0) return NFL_OK;
+    PackBatch B;
+    B.n = n_jobs;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const nfl_pack_job& J = jobs[j];
+        const NflPlan* hp = static_cast<const NflPlan*>(J.h_plan);
+        if (!hp || !J.d_plan || !J.params || !J.d_packed || hp->magic != NFL_PLAN_MAGIC) return NFL_EINVAL;
+        if (J.packed_bytes < (size_t)hp->packed_bytes) return NFL_ESMALL;
+        B.first_block[j] = blocks;
+        blocks += hp->total_ks + hp->n_rt;
+        B.job[j].plan = static_cast<const NflPlan*>(J.d_plan);
+        B.job[j].params = *J.params;
+        B.job[j].out = static_cast<char*>(J.d_packed);
+        B.job[j].status = J.d_status;
+    }
+    B.first_block[n_jobs] = blocks;
+    hipLaunchKernelGGL(nfl_pack_kernel, dim3(blocks), dim3(64), 0, static_cast<hipStream_t>(stream), B);
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}
+
 extern "C" int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_params* params,
                               void* d_packed, size_t packed_bytes, int32_t* d_status, void* stream) {
-    const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
-    if (!hp || !d_plan || !params || !d_packed || hp->magic != NFL_PLAN_MAGIC) return NFL_EINVAL;
-    if (packed_bytes < (size_t)hp->packed_bytes) return NFL_ESMALL;
-    PackArgs a;
-    a.plan = static_cast<const NflPlan*>(d_plan);
-    a.params = *params;
-    a.out = static_cast<char*>(d_packed);
-    a.status = d_status;
-    hipLaunchKernelGGL(nfl_pack_kernel, dim3(hp->total_ks + hp->n_rt), dim3(64), 0,
-                       static_cast<hipStream_t>(stream), a);
-    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+    nfl_pack_job J;
+    J.h_plan = h_plan;
+    J.d_plan = d_plan;
+    J.params = params;
+    J.d_packed = d_packed;
+    J.packed_bytes = packed_bytes;
+    J.d_status = d_status;
+    return nfl_pack_fields(1, &J, stream);
 }

@@ -181,8 +181,8 @@ class _PackedField:
                 out.append((i, params[name + ".weight"], params[name + ".bias"]))
         return out
 
-    def ensure_bwd_packed(self, rays_grad=False):
-        """dgrad stream (transposed weights, fp16) for the current parameters."""
+    def bwd_plan(self, rays_grad=False):
+        """Plan + buffer of the dgrad stream (transposed weights, fp16); packed by ensure_bwd_packed / _pack_streams."""
         L = _lib.lib()
         rg = int(bool(rays_grad))
         if rg not in self.bplans:
@@ -192,7 +192,12 @@ class _PackedField:
             pb = L.nfl_bwd_packed_bytes(C.byref(self.desc), rg)
             self.bplans[rg] = dict(h=h, d=torch.frombuffer(bytearray(h.raw), dtype=torch.uint8).to(self.device),
                                    packed=torch.empty(pb, dtype=torch.uint8, device=self.device), nbytes=pb, key=None)
-        bp = self.bplans[rg]
+        return self.bplans[rg]
+
+    def ensure_bwd_packed(self, rays_grad=False):
+        """dgrad stream for the current parameters (the forward stream must be current: self.key)."""
+        L = _lib.lib()
+        bp = self.bwd_plan(rays_grad)
         if bp["key"] != self.key:
             fp, _keep = self._field_params()
             _lib.check(L.nfl_pack_field(bp["h"], _ptr(bp["d"]), C.byref(fp), _ptr(bp["packed"]), bp["nbytes"],
@@ -216,10 +221,11 @@ class _PackedField:
             fp.bias[i] = b.data_ptr()
         return fp, keep
 
+    def current_key(self):
+        return tuple((n, p.data_ptr(), p._version) for n, p in self.model_ref().named_parameters())
+
     def ensure_packed(self):
-        model = self.model_ref()
-        params = dict(model.named_parameters())
-        key = tuple((n, p.data_ptr(), p._version) for n, p in params.items())
+        key = self.current_key()
         if key == self.key:
             return
         fp, _keep = self._field_params()
@@ -233,15 +239,49 @@ _fields = weakref.WeakKeyDictionary()
 _lin_cache = {}
 
 
-def _field(model, n_emb_xyz, n_emb_dir, device):
+def _field(model, n_emb_xyz, n_emb_dir, device, pack=True):
     prec = _PREC[_precision]
     slot = _fields.setdefault(model, {})
     k = (prec, str(device), n_emb_xyz, n_emb_dir)
     if k not in slot:
         slot[k] = _PackedField(model, n_emb_xyz, n_emb_dir, prec, device)
     f = slot[k]
-    f.ensure_packed()
+    if pack:
+        f.ensure_packed()
     return f
+
+
+def _pack_streams(fields, bwd, rays_grad):
+    """Bring the forward (and, for a training call, the dgrad) weight streams of `fields` up to date with ONE
+    nfl_pack_fields launch: after an optimizer step all four streams of a coarse + fine pair are stale."""
+    jobs, done, keep = [], [], []
+    for f in fields:
+        if f is None or any(f is g for g, _ in done):
+            continue
+        key = f.current_key()
+        done.append((f, key))
+        stale_fwd = key != f.key
+        bp = f.bwd_plan(rays_grad) if bwd else None
+        stale_bwd = bp is not None and bp["key"] != key
+        if not (stale_fwd or stale_bwd):
+            continue
+        fp, tensors = f._field_params()
+        keep += [fp, tensors]
+        if stale_fwd:
+            jobs.append((f, None, key, _lib.PackJob(C.cast(f.h_plan, C.c_void_p), _ptr(f.d_plan), C.pointer(fp), _ptr(f.packed),
+                                                    f.packed_bytes, _ptr(_status_word(f.device)))))
+        if stale_bwd:
+            jobs.append((f, bp, key, _lib.PackJob(C.cast(bp["h"], C.c_void_p), _ptr(bp["d"]), C.pointer(fp), _ptr(bp["packed"]),
+                                                  bp["nbytes"], C.c_void_p(0))))
+    for i in range(0, len(jobs), _lib.NFL_PACK_MAX_JOBS):
+        part = jobs[i:i + _lib.NFL_PACK_MAX_JOBS]
+        arr = (_lib.PackJob * len(part))(*[j[3] for j in part])
+        _lib.check(_lib.lib().nfl_pack_fields(len(part), arr, _stream()), "nfl_pack_fields")
+    for f, bp, key, _ in jobs:
+        if bp is None:
+            f.key = key
+        else:
+            bp["key"] = key
 
 
 def field_forward(model, x, sigma_only=False, output_transient=True):
@@ -608,7 +648,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
             raise NotImplementedError("gradient w.r.t. rays with a separate view_dir")
         if kwargs.get("view_dir") is not None:
             cfg["view_dir"] = _f32c(kwargs["view_dir"], "view_dir", (R, 3))
-        cfg["f_c"] = _field(models["coarse"], n_xyz, n_dir, dev)
+        cfg["f_c"] = _field(models["coarse"], n_xyz, n_dir, dev, pack=False)      # packed below, all streams in one launch
         # random draws, in the reference's order (rendering.py:258, 151, 30, 151)
         if perturb > 0:
             pr = kwargs.get("perturb_rand")
@@ -629,7 +669,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                 u = kwargs.get("u")
                 cfg["u"] = torch.rand(R, I, device=dev) if u is None else _f32c(u, "u", (R, I))
             fine = models["fine"]
-            cfg["f_f"] = f_f = _field(fine, n_xyz, n_dir, dev)
+            cfg["f_f"] = f_f = _field(fine, n_xyz, n_dir, dev, pack=False)
             params += [p for _, w, b in f_f.param_list() for p in (w, b)]
             cfg["use_t"] = bool(kwargs.get("output_transient", True) and fine.encode_transient)
             # Latent codes (rendering.py:276-286).  When every code in use comes from a plain nn.Embedding and a gradient
@@ -669,6 +709,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
         needs_grad = torch.is_grad_enabled() and (
             rays_grad or any(p.requires_grad for p in params)
             or any(t is not None and t.requires_grad for t in (a_emb, t_emb)))
+        _pack_streams([cfg["f_c"], cfg["f_f"]], bwd=needs_grad and not test_time and _precision == "f16x3", rays_grad=rays_grad)
         if cfg["loss"] is not None and not (torch.is_grad_enabled() and not test_time):
             raise RuntimeError("loss_target fuses the loss into the TRAINING passes: call it with gradients enabled")
         if needs_grad:
