@@ -584,6 +584,8 @@ class _RenderRaysFn(torch.autograd.Function):
         if cfg["loss"] is not None:                     # only the total carries gradient in this mode
             ctx.mark_non_differentiable(*[result[k] for k in keys if k != "_nerfw_loss"])
         ctx.cfg, ctx.keys, ctx.saved, ctx.rays = cfg, keys, saved, rays
+        # the backward reads the fp32 weights again (dgrad stream, composed gradients): they must still be the forward's
+        ctx.param_keys = [f.current_key() for f in (cfg["f_c"], cfg["f_f"]) if f is not None]
         ctx.a_emb, ctx.t_emb = a_emb, t_emb
         ctx.extra = {k: v for k, v in result.items() if k not in keys}
         return tuple(result[k] for k in keys)
@@ -591,6 +593,9 @@ class _RenderRaysFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         cfg, keys, saved, rays = ctx.cfg, ctx.keys, ctx.saved, ctx.rays
+        if ctx.param_keys != [f.current_key() for f in (cfg["f_c"], cfg["f_f"]) if f is not None]:
+            raise RuntimeError("nerf_fl_amd.render_rays: a parameter of the field was modified in place between the forward "
+                               "and the backward pass; the hand-written backward needs the weights the forward ran with")
         with torch.cuda.device(rays.device):
             out = []
             g_a = g_t = None

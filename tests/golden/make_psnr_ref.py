@@ -29,7 +29,7 @@ from losses import loss_dict                          # noqa: E402  (reference)
 import psnr_scene as sc                               # noqa: E402  (tests/psnr_scene.py: inputs shared with the GPU test)
 from oracle import nerfw_oracle as orc                # noqa: E402
 
-torch.set_num_threads(8)
+torch.set_num_threads(int(os.environ.get("NFL_REF_THREADS", "8")))
 
 
 class InjectRandom:
@@ -49,7 +49,7 @@ class InjectRandom:
         assert not self.draws, "the reference drew fewer tensors than prepared"
 
 
-def run(kind, perturb=0.0, replica=1):
+def run(kind, perturb=0.0, replica=1, grad_noise=0.0):
     """perturb > 0: a replica whose initial weights are multiplied by (1 + perturb * N(0,1)) -- how far the REFERENCE
     moves from itself under rounding-level differences; stored as psnr_<kind>_replica[2].npz."""
     cfg = sc.CONFIGS[kind]
@@ -75,6 +75,7 @@ def run(kind, perturb=0.0, replica=1):
             emb[k] = e
             params += list(e.parameters())
     opt = torch.optim.Adam(params, lr=cfg["lr"], eps=1e-8)
+    gn = torch.Generator().manual_seed(777 + replica)
     loss_fn = loss_dict["nerfw"]()
     models = {"coarse": mc, "fine": mf}
     losses = []
@@ -89,6 +90,10 @@ def run(kind, perturb=0.0, replica=1):
             res = render_rays(models, emb, rays, ts, S, False, 1.0, 1.0, I, 32768, True, False)
         loss = sum(loss_fn(res, target).values())
         loss.backward()
+        if grad_noise > 0:      # experiment: a noise floor of grad_noise * max|g| per tensor on every gradient, as a
+            for p_ in params:   # reduced-precision backward leaves (tests/test_psnr_parity_gpu.py discusses the outcome)
+                if p_.grad is not None:
+                    p_.grad.add_(grad_noise * p_.grad.abs().max() * torch.randn(p_.grad.shape, generator=gn))
         opt.step()
         losses.append(float(loss))
         if it % 25 == 0 or it == steps - 1:
@@ -99,15 +104,19 @@ def run(kind, perturb=0.0, replica=1):
     psnr = float(-10.0 * torch.log10(((res["rgb_fine"] - target) ** 2).mean()))
     print(f"[{kind}] validation PSNR of the reference-trained model: {psnr:.3f} dB")
     tag = f"psnr_{kind}" + (("_replica" + ("" if replica == 1 else str(replica))) if perturb > 0 else "")
+    if grad_noise > 0:
+        tag = f"psnr_{kind}_gradnoise{replica}"
     np.savez_compressed(os.path.join(HERE, tag + ".npz"), cfg=json.dumps(cfg), losses=np.asarray(losses, np.float32),
-                        val_psnr=np.float32(psnr), perturb=np.float32(perturb))
+                        val_psnr=np.float32(psnr), perturb=np.float32(perturb), grad_noise=np.float32(grad_noise))
 
 
 if __name__ == "__main__":
+    import re
     for kind in (sys.argv[1:] or ["base", "nerfw"]):
-        if kind.endswith("_replica"):
-            run(kind[:-8], perturb=1e-6)
-        elif kind.endswith("_replica2"):
-            run(kind[:-9], perturb=1e-6, replica=2)
+        m = re.fullmatch(r"(base|nerfw)_(replica|gradnoise)(\d*)", kind)
+        if m and m.group(2) == "replica":          # base_replica, base_replica2, base_replica3, ...
+            run(m.group(1), perturb=1e-6, replica=int(m.group(3) or 1))
+        elif m:                                    # base_gradnoise1, ...: the reference with a 1e-3 gradient noise floor
+            run(m.group(1), replica=int(m.group(3) or 1), grad_noise=1e-3)
         else:
             run(kind)

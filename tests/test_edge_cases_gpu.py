@@ -49,3 +49,24 @@ def test_argument_errors():
             render_rays(models, emb, rays[:, :6], ts, 8)
         with pytest.raises(ValueError):                    # embedding width does not match the model
             render_rays(models, {"xyz": PosEmbedding(14, 15), "dir": PosEmbedding(3, 4)}, rays, ts, 8)
+
+
+def test_parameters_modified_between_forward_and_backward():
+    """The hand-written backward reads the weights again (dgrad stream; the gradients around xyz_encoding_final are
+    composed from the fp32 weights): like autograd's saved-tensor version check it refuses weights that changed."""
+    import gpu_util
+    from nerf_fl_amd import NeRF, PosEmbedding, render_rays
+    dev = gpu_util.DEV
+    models = {"coarse": NeRF("coarse").to(dev), "fine": NeRF("fine").to(dev)}
+    emb = {"xyz": PosEmbedding(9, 10), "dir": PosEmbedding(3, 4)}
+    rays = orc.make_rays(8, 1).to(dev)
+    ts = torch.zeros(8, dtype=torch.long, device=dev)
+    res = render_rays(models, emb, rays, ts, 8, False, 0, 0, 8)
+    loss = res["rgb_fine"].sum() + res["rgb_coarse"].sum()
+    with torch.no_grad():
+        models["fine"].xyz_encoding_final.weight.mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        loss.backward()
+    res = render_rays(models, emb, rays, ts, 8, False, 0, 0, 8)         # an untouched pair of passes still works
+    (res["rgb_fine"].sum() + res["rgb_coarse"].sum()).backward()
+    assert models["fine"].xyz_encoding_final.weight.grad is not None

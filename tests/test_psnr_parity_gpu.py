@@ -76,37 +76,40 @@ def test_fit_psnr_matches_oracle():
 # validation PSNR; tests/psnr_scene.py regenerates the inputs on both sides).
 # ---------------------------------------------------------------------------------------------------------------------
 # How close can two correct implementations be?  Training is chaotic: the reference, re-run here with its initial
-# weights perturbed by 1e-6 relative (fp32 rounding level; psnr_*_replica*.npz), ends 0.1-0.2 dB away from ITSELF after
-# these 600 steps, and its windowed loss curve moves by ~2 %.  The test therefore allows 0.1 dB (BASELINE.json) on top of
-# the reference's own measured spread (largest pairwise difference among the reference run and its two replicas).
-# The HIP run is not deterministic either (fp32 atomics' order): over 4 launches of this test its validation PSNR was
-# 21.96 .. 22.11 dB (base; reference and replicas 21.88 .. 22.21) and 18.47 .. 18.52 dB (NeRF-W; 18.40 .. 18.44).
-# Training loss, windowed over 50 steps: the HIP-trained curve sits 3 .. 4 % BELOW the reference's on the base scene in
-# every launch (final window 0.00672 .. 0.00681 against 0.00701 .. 0.00715 for the three reference runs) and 0.3 .. 0.7 %
-# below on NeRF-W.  It is a late-phase effect: over the first 80 steps the HIP run tracks the reference curve to 2e-4
-# relative per 10-step window and 1e-6 per step (tests/report_psnr_curve.py), i.e. no bias of the mixed-precision
-# backward is visible before the trajectories decorrelate (which the reference's own replicas do at the same step,
-# by the same +-1..3 %); what differs afterwards is that the HIP gradients carry ~1e-3 of fresh rounding noise at every
-# step while a replica is perturbed once.  It does not show in validation PSNR.  The band on the windowed curves is 6 %.
+# weights perturbed by 1e-6 relative (fp32 rounding level; psnr_*_replica*.npz), ends with a validation PSNR that scatters
+# with sigma ~ 0.12 dB around its mean after these 600 steps (base: 21.88 .. 22.21 dB over the stored runs), and the HIP
+# fit -- not deterministic either, its weight gradients are accumulated with fp32 atomics -- scatters by the same amount
+# (21.81 .. 22.32 dB over 27 launches).  One run against one run cannot resolve 0.1 dB (BASELINE.json), so the test
+# compares ENSEMBLES: the mean over N_HIP_RUNS HIP fits against the mean over all stored reference runs, allowing 0.1 dB
+# plus three standard errors of that difference.  Measured: base 22.05 (HIP, 27 runs) vs 22.00 dB (reference, 6 runs).
+#
+# Training loss, windowed over 50 steps.  Over the first 100 steps the HIP curve is the reference's (2e-4 per 10-step
+# window, 1e-6 per step: tests/report_psnr_curve.py).  Later the HIP curve drifts BELOW the reference's, in every launch
+# and gradually: -1.5 % around step 300, -3 % around 400, -4 .. -6 % in the last windows (base scene; < 1 % on NeRF-W),
+# where the reference's own replicas stay within 1 % of each other.  This is not an error of the kernels -- along a HIP
+# trajectory the loss equals the fp32 forward's to 1e-7 and the gradient's cosine with fp32 autograd is 1 - 1e-8, worst
+# tensor 4e-3 relative (tests/report_psnr_fwdcheck.py) -- and not the optimizer (the fp32 oracle trained ON THE GPU follows
+# the CPU reference to 0.5 % with torch's Adam and to 0.2 % with this package's, tests/report_psnr_oracle_gpu.py).  It is
+# what Adam does with a small PERSISTENT additive error on the gradients: the same fp32 oracle with one fixed noise
+# pattern of 3e-4 of each tensor's norm -- the size of the fp16 backward's error, whose pattern is persistent too (weights
+# and activations rounded to fp16 change slowly) -- added to its gradients at every step drifts the same way in three of
+# three runs (-3 % at step 400, -5.9 / -6.7 / -6.7 % in the last window); fresh white noise of that size drifts the same
+# way on average but not every time (-5.1 .. +0.5 % over seven runs), and a multiplicative perturbation does not (+-2 %).
+# (A much larger floor, 1e-3 of max|g| per element, hurts: +8 % loss, -0.3 dB, on the GPU and in the reference itself,
+# psnr_base_gradnoise*.npz.)  profiles/r02_psnr_drift_control.txt holds these runs.  The validation PSNR does not move
+# with it.  The test therefore pins the first 100 steps tightly (0.5 %) and allows 8 % on the mean curve later.
+N_HIP_RUNS = 4
 
 
-@pytest.mark.parametrize("kind", ["base", "nerfw"])
-def test_fit_psnr_matches_reference_64_64(kind):
-    import json
-    import os
-
-    import numpy as np
-
-    import golden_util as gu
+def fit_64_64(kind, _grad_noise=0.0, _loss="hip", _adam="hip"):
+    """One 600-step fit with the HIP renderer on the stored batches / draws.  Returns (loss per step, validation PSNR)."""
     import gpu_util
     import psnr_scene as sc
     from nerf_fl_amd import PosEmbedding, render_rays
     from nerf_fl_amd.train import Adam, NerfWLoss
     dev = gpu_util.DEV
-    ref = np.load(os.path.join(gu.GOLDEN_DIR, f"psnr_{kind}.npz"), allow_pickle=False)
-    cfg = json.loads(str(ref["cfg"]))
-    assert cfg == sc.CONFIGS[kind], "the stored reference run was made with other hyper-parameters"
-    S, I, R, steps = cfg["S"], cfg["I"], cfg["R"], cfg["steps"]
+    cfg = sc.CONFIGS[kind]
+    S, I, steps = cfg["S"], cfg["I"], cfg["steps"]
     nerfw = cfg["fine"] == "at"
     spec_c = orc.FieldSpec("coarse")
     spec_f = orc.FieldSpec("fine", encode_appearance=nerfw, encode_transient=nerfw, beta_min=0.1)
@@ -120,8 +123,8 @@ def test_fit_psnr_matches_reference_64_64(kind):
             e.weight.data.copy_(orc.make_embedding_table(cfg["n_vocab"], dim, cfg["seed"] + off))
             emb[k] = e
             params += list(e.parameters())
-    opt = Adam(params, lr=cfg["lr"], eps=1e-8)
-    loss_fn = NerfWLoss()
+    opt = Adam(params, lr=cfg["lr"], eps=1e-8) if _adam == "hip" else torch.optim.Adam(params, lr=cfg["lr"], eps=1e-8)
+    loss_fn = NerfWLoss() if _loss == "hip" else orc.nerfw_loss      # report scripts swap single ingredients
     losses = []
     for it in range(steps):
         rays, ts, target = sc.batch(cfg, it)
@@ -134,27 +137,62 @@ def test_fit_psnr_matches_reference_64_64(kind):
         res = render_rays(models, emb, rays.to(dev), ts.to(dev), S, False, 1.0, 1.0, I, 32768, True, False, **d)
         loss = sum(loss_fn(res, target.to(dev)).values())
         loss.backward()
+        if _grad_noise > 0:      # tests/report_psnr_repeat.py: an extra noise floor on every gradient tensor
+            for p_ in params:
+                if p_.grad is not None:
+                    p_.grad.add_(_grad_noise * p_.grad.abs().max() * torch.randn_like(p_.grad))
         opt.step()
         losses.append(loss.detach())
     losses = torch.stack(losses).cpu().numpy()
     rays, ts, target = sc.val_batch(cfg)
     with torch.no_grad():
         out = render_rays(models, emb, rays.to(dev), ts.to(dev), S, False, 0, 0.0, I, 32768, True, False)
-    psnr_hip = orc.psnr(out["rgb_fine"].cpu(), target)
-    psnr_ref = float(ref["val_psnr"])
-    win = 50
-    wmean = lambda x: np.asarray(x)[: steps // win * win].reshape(-1, win).mean(1)
-    m_hip, m_ref = wmean(losses), wmean(ref["losses"])
-    dev_rel = np.abs(m_hip - m_ref) / np.abs(m_ref)
-    reps = [np.load(os.path.join(gu.GOLDEN_DIR, f"psnr_{kind}_replica{s}.npz"), allow_pickle=False) for s in ("", "2")]
-    psnrs = [psnr_ref] + [float(r["val_psnr"]) for r in reps]
-    spread = max(psnrs) - min(psnrs)
-    loss_spread = max(float((np.abs(wmean(r["losses"]) - m_ref) / np.abs(m_ref)).max()) for r in reps)
-    print(f"[{kind}] validation PSNR: reference-trained {psnr_ref:.3f} dB, HIP-trained {psnr_hip:.3f} dB; first-step loss "
-          f"{losses[0]:.6f} vs {ref['losses'][0]:.6f}; windowed loss curves differ by at most {100 * dev_rel.max():.2f} % "
-          f"(final window {m_hip[-1]:.5f} vs {m_ref[-1]:.5f}); the reference's own replicas: PSNR {psnrs[1]:.3f} / {psnrs[2]:.3f} dB "
-          f"(spread {spread:.3f} dB), windowed loss deviation {100 * loss_spread:.2f} %")
-    assert abs(float(losses[0]) - float(ref["losses"][0])) <= 1e-4 * max(1.0, abs(float(ref["losses"][0]))), "same first step"
-    assert psnr_ref > 15.0, "the reference fit did not learn anything; the comparison would be vacuous"
-    assert abs(psnr_ref - psnr_hip) <= 0.1 + spread
-    assert dev_rel.max() <= max(0.06, 2.0 * loss_spread)
+    return losses, orc.psnr(out["rgb_fine"].cpu(), target)
+
+
+def reference_runs(kind):
+    """Every stored run of the REAL reference on this scene: the plain one and its 1e-6-perturbed replicas."""
+    import glob
+    import os
+
+    import numpy as np
+
+    import golden_util as gu
+    files = [os.path.join(gu.GOLDEN_DIR, f"psnr_{kind}.npz")] + sorted(glob.glob(os.path.join(gu.GOLDEN_DIR, f"psnr_{kind}_replica*.npz")))
+    return [np.load(f, allow_pickle=False) for f in files]
+
+
+@pytest.mark.parametrize("kind", ["base", "nerfw"])
+def test_fit_psnr_matches_reference_64_64(kind):
+    import json
+
+    import numpy as np
+
+    import psnr_scene as sc
+    refs = reference_runs(kind)
+    assert len(refs) >= 3
+    for r in refs:
+        assert json.loads(str(r["cfg"])) == sc.CONFIGS[kind], "a stored reference run was made with other hyper-parameters"
+    steps, win = sc.CONFIGS[kind]["steps"], 50
+    wmean = lambda x: np.asarray(x, np.float64)[: steps // win * win].reshape(-1, win).mean(1)
+    ref_psnr = np.array([float(r["val_psnr"]) for r in refs])
+    ref_curves = np.stack([wmean(r["losses"]) for r in refs])
+    runs = [fit_64_64(kind) for _ in range(N_HIP_RUNS)]
+    hip_psnr = np.array([p for _, p in runs])
+    hip_curves = np.stack([wmean(l) for l, _ in runs])
+    # validation PSNR: ensemble means, 0.1 dB + 3 standard errors (sample sigmas floored at 0.08 dB: three or four runs
+    # can land close together by chance)
+    s_ref, s_hip = max(ref_psnr.std(ddof=1), 0.08), max(hip_psnr.std(ddof=1), 0.08)
+    se = float(np.sqrt(s_ref ** 2 / len(ref_psnr) + s_hip ** 2 / len(hip_psnr)))
+    dev_rel = (hip_curves.mean(0) - ref_curves.mean(0)) / ref_curves.mean(0)
+    print(f"[{kind}] validation PSNR: reference {ref_psnr.mean():.3f} dB over {len(refs)} runs ({' '.join(f'{v:.2f}' for v in ref_psnr)}), "
+          f"HIP {hip_psnr.mean():.3f} dB over {len(runs)} runs ({' '.join(f'{v:.2f}' for v in hip_psnr)}); standard error of the "
+          f"difference {se:.3f} dB; mean windowed loss curve vs the reference's (%): {' '.join(f'{100 * v:.2f}' for v in dev_rel)}; "
+          f"the reference runs among themselves (rel. std, %): {' '.join(f'{100 * v:.2f}' for v in ref_curves.std(0, ddof=1) / ref_curves.mean(0))}")
+    for l, _ in runs:
+        assert abs(float(l[0]) - float(refs[0]["losses"][0])) <= 1e-4 * max(1.0, abs(float(refs[0]["losses"][0]))), "same first step"
+    assert ref_psnr.mean() > 15.0, "the reference fit did not learn anything; the comparison would be vacuous"
+    assert abs(hip_psnr.mean() - ref_psnr.mean()) <= 0.1 + 3.0 * se
+    assert np.abs(hip_psnr - ref_psnr.mean()).max() <= 0.1 + 5.0 * max(s_ref, s_hip), "a single run far outside the scatter"
+    assert np.abs(dev_rel[:2]).max() <= 0.005, "the first 100 steps follow the reference's curve"
+    assert np.abs(dev_rel).max() <= 0.08
