@@ -134,6 +134,10 @@ def test_auxiliary_entry_points_validate_arguments(L):
     assert L.nfl_composite_backward(None, None) == -1 and L.nfl_mlp_dgrad(None, None, None, None, None) == -1
     assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, None, None, None, None) == -1
     assert L.nfl_wgrad_scratch_bytes() == 256 * 256 * 4
+    assert L.nfl_pack_fields(0, None, None) == 0                                            # nothing to do
+    assert L.nfl_pack_fields(1, None, None) == -1 and L.nfl_pack_fields(_lib.NFL_PACK_MAX_JOBS + 1, None, None) == -1
+    job = (_lib.PackJob * 1)()                                                              # a job without a plan
+    assert L.nfl_pack_fields(1, job, None) == -1
 
 
 def test_adam_step_dev_validates_arguments(L):
