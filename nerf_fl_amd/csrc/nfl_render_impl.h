@@ -558,12 +558,7 @@ struct NflActEpi {
 
 // A dense layer of NRT row tiles reading inA[ksA0..+NKA) then inB[ksB0..+NKB), TPC tiles per
 // ring chunk.  The epilogue of tile i-1 rides in the MFMA shadows of tile i.
-// E0 / E1: VMEM stores the CALLER knows to have been issued after the last LDS-DMA piece of this layer's first / second
-// chunk (the stash stores of the previous layer's last epilogues, which ride in its last tile and sit exposed after it):
-// consume() may leave them outstanding.  Without them the counted wait at every layer boundary also waited for those
-// stores' HBM acknowledgements -- most of what the activation stash cost the training forward.  An over-count would let
-// a wave read a ring slot before its pieces have landed: they are exact lower bounds, derived at the call sites.
-template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool STASH, int E0 = 0, int E1 = 0, int NINA, int NINB, int NOUT, class Ring>
+template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool STASH, int NINA, int NINB, int NOUT, class Ring>
 NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
                        const h8 (&inA)[NINA][NCB][NP], int ksA0,
                        const h8 (&inB)[NINB][NCB][NP], int ksB0,
@@ -582,10 +577,8 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
     };
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        // chunk c = i / TPC: its pieces were issued while chunk c-2 was consumed; the tiles of chunk c-1 carried the stash
-        // stores of the epilogues of the TPC tiles before them, issued after this chunk's pieces
-        constexpr int c = i / TPC;
-        if (i % TPC == 0) wl = ring.template consume<(c == 0 ? E0 : (c == 1 ? E1 : (STASH ? TPC * NST : 0)))>();
+        // tile i-1 carried the stash stores of tile i-2's epilogue, issued after this chunk's pieces
+        if (i % TPC == 0) wl = ring.template consume<(STASH && TPC == 1 && i >= 2) ? NST : 0>();
         constexpr int frag0 = (i % TPC) * NK;
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         if constexpr (i > 0) {
@@ -599,19 +592,15 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         if (i % TPC == TPC - 1 || i == NRT - 1) ring.template pieces<((i % TPC) + 1) * NK, Ring::MAXP>();
     });
     NflActEpi<NP, NCB, RELU, STASH, NOUT, (NRT - 1) & 3> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1, mq, ring.ovf};
-#ifdef NFL_ABL_NOLAST       // timing ablation (results wrong): how much of a tile is the exposed epilogue of a layer's last row tile?
-    last.template pair<0>();
-#else
     last.all();
-#endif
     rt += NRT;
 }
 
 // a single head tile (own chunk); the caller interprets the accumulator rows
-template <int NP, int NCB, int NK, int E0 = 0, int NIN, class Ring>
+template <int NP, int NCB, int NK, int NIN, class Ring>
 NFL_DEV void nfl_head(Ring& ring, const float* bias_lds, int& rt, int h,
                       const h8 (&in)[NIN][NCB][NP], int ks0, f16v (&acc)[NCB]) {
-    const char* wl = ring.template consume<E0>();      // E0: as in nfl_dense
+    const char* wl = ring.consume();
     nfl_bias_init<NP, NCB>(acc, bias_lds + rt * 32, h);
     auto getb = [&](auto K, int cb, int part) __attribute__((always_inline)) -> const h8& {
         return in[ks0 + decltype(K)::value][cb][part];
@@ -864,29 +853,23 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         NFL_STAMP(0);
         nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1), mst, nfl_msk_h(1));       // L1
         NFL_STAMP(1);
-        // stash stores younger than a layer's first chunks (nfl_dense: E0 / E1).  An 8-tile relu layer issues per epilogue
-        // SE = 2 NCB activation stores, and NCB mask stores with the epilogues of tiles 3 and 7.  Chunk sequence
-        // ... t5 t6 t7 | t0' t1': the pieces of t0' are issued during t6, those of t1' during t7; t7 carries the epilogue of
-        // t6 and is followed by its own (+ masks): E0 = 2 SE + SM, E1 = SE + SM.  L1 has two tiles per chunk (the pieces of
-        // L2's first chunk are issued during its tiles 4-5, so tiles 6-7 carry two more epilogues): E0 = 3 SE + SM.
-        constexpr int SE = STASH ? 2 * NCB : 0, SM = STASH ? NCB : 0;
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, 3 * SE + SM, SE + SM>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2), mst, nfl_msk_h(2));        // L2
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2), mst, nfl_msk_h(2));        // L2
         NFL_STAMP(2);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, 2 * SE + SM, SE + SM>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3), mst, nfl_msk_h(3));        // L3
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3), mst, nfl_msk_h(3));        // L3
         NFL_STAMP(3);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, 2 * SE + SM, SE + SM>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4), mst, nfl_msk_h(4));        // L4
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4), mst, nfl_msk_h(4));        // L4
         NFL_STAMP(4);
-        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH, 2 * SE + SM, SE + SM>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5), mst, nfl_msk_h(5));      // L5 (skip)
+        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5), mst, nfl_msk_h(5));      // L5 (skip)
         NFL_STAMP(5);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, 2 * SE + SM, SE + SM>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6), mst, nfl_msk_h(6));        // L6
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6), mst, nfl_msk_h(6));        // L6
         NFL_STAMP(6);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, 2 * SE + SM, SE + SM>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7), mst, nfl_msk_h(7));        // L7
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7), mst, nfl_msk_h(7));        // L7
         NFL_STAMP(7);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, 2 * SE + SM, SE + SM>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8), mst, nfl_msk_h(8));        // L8
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8), mst, nfl_msk_h(8));        // L8
         NFL_STAMP(8);
         {
             f16v hacc[NCB];
-            nfl_head<NP, NCB, 16, 2 * SE + SM>(ring, bias_lds, rt, h, Y, 0, hacc);                          // sigma (the tile after L8's t7)
+            nfl_head<NP, NCB, 16>(ring, bias_lds, rt, h, Y, 0, hacc);                          // sigma
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) o_sig[cb] = hacc[cb][0];
         }
@@ -895,8 +878,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         if (!K->a.sigma_only) {
             // final (linear).  Never stashed: the weight gradients that would read it are composed from
             // G = sum_s delta_dirh (x) h8 instead (nfl_wgrad.hip: "composed through xyz_encoding_final")
-            // (its first chunk's pieces are issued during L8's t7, which L8's last epilogue follows; its second chunk's during the sigma tile)
-            nfl_dense<NP, NCB, 16, 0, false, 8, 1, false, SE + SM, 0>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, 0, mst, 0);
+            nfl_dense<NP, NCB, 16, 0, false, 8, 1, false>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, 0, mst, 0);
             NFL_STAMP(10);
             {
                 h8 D[5][NCB][NP];
