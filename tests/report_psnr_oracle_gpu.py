@@ -20,6 +20,45 @@ which_adam = ([a[5:] for a in sys.argv[2:] if a.startswith("adam=")] or ["torch"
 rel_noise = float(([a[4:] for a in sys.argv[2:] if a.startswith("rel=")] or ["0"])[0])
 frozen_noise = float(([a[7:] for a in sys.argv[2:] if a.startswith("frozen=")] or ["0"])[0])
 elem_noise = float(([a[5:] for a in sys.argv[2:] if a.startswith("elem=")] or ["0"])[0])
+# bwd=w16: every Linear's backward multiplies by the fp16-ROUNDED weight (what the HIP dgrad does; the rounding pattern is
+# persistent); bwd=a16: the weight gradient uses fp16-rounded input activations and output gradients (what the HIP wgrad does)
+bwd_mode = ([a[4:] for a in sys.argv[2:] if a.startswith("bwd=")] or [""])[0]
+
+
+_scale = [None]
+
+
+class _LinearLowBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        wq = w.half().float() if "w16" in bwd_mode else w
+        if "chain" in bwd_mode:
+            # one loss scale per step, fixed by the first (head) layer the backward reaches, like the HIP pass' d_gmax;
+            # the fp16-rounded gradient is what propagates AND what enters the weight gradient
+            if _scale[0] is None:
+                _scale[0] = 32.0 / g.abs().max().clamp_min(1e-30)
+            s = _scale[0]
+            gq, xq = (g * s).half().float() / s, x.half().float()
+            gx = gq @ wq
+        elif "a16" in bwd_mode:
+            s = 32.0 / g.abs().max().clamp_min(1e-30)                  # the loss scale: max -> 2^5
+            gq, xq = (g * s).half().float() / s, x.half().float()
+            gx = g @ wq
+        else:
+            gq, xq = g, x
+            gx = g @ wq
+        g2, x2 = gq.reshape(-1, gq.shape[-1]), xq.reshape(-1, xq.shape[-1])
+        return gx, g2.t() @ x2, g2.sum(0)
+
+
+if bwd_mode:
+    orc._lin = lambda P, name, x: _LinearLowBwd.apply(x, P[name + ".weight"], P[name + ".bias"])
 kind = "base"
 cfg = sc.CONFIGS[kind]
 S, I, steps = cfg["S"], cfg["I"], cfg["steps"]
@@ -49,6 +88,7 @@ for run in range(n):
         res = orc.render_rays(spec_c, P_c, spec_f, P_f, rays.to(dev), n_samples=S, n_importance=I, perturb=1.0, noise_std=1.0,
                               white_back=True, **d)
         loss = sum(orc.nerfw_loss(res, target.to(dev)).values())
+        _scale[0] = None
         loss.backward()
         if rel_noise > 0:      # white noise of relative l2 size rel_noise on every gradient tensor, fresh every step
             for p_ in params:
@@ -66,5 +106,5 @@ for run in range(n):
         losses.append(loss.detach())
     torch.set_default_device("cpu")
     losses = torch.stack(losses).cpu().numpy()
-    print(f"oracle-on-GPU ({which_adam} Adam, rel {rel_noise} frozen {frozen_noise} elem {elem_noise}) run {run}: first loss {losses[0]:.6f} (ref {refs[0]['losses'][0]:.6f}); dev (%)",
+    print(f"oracle-on-GPU ({which_adam} Adam, bwd {bwd_mode or chr(45)}, rel {rel_noise} frozen {frozen_noise} elem {elem_noise}) run {run}: first loss {losses[0]:.6f} (ref {refs[0]['losses'][0]:.6f}); dev (%)",
           " ".join(f"{100 * (a - b) / b:7.2f}" for a, b in zip(wmean(losses), Rm)), flush=True)
