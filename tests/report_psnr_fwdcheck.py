@@ -34,7 +34,7 @@ for it in range(steps):
     res = render_rays(models, emb, rays.to(dev), ts.to(dev), S, False, 1.0, 1.0, I, 32768, True, False, **d)
     loss = sum(orc.nerfw_loss(res, target.to(dev)).values())
     loss.backward()
-    if it % 50 == 0 or it == steps - 1:
+    if it % 50 == 0 or it % 50 == 1 or it == steps - 1:
         # the oracle on the same weights (detached copies with their own autograd graph)
         Pc = {n: p.detach().clone().requires_grad_(True) for n, p in models["coarse"].named_parameters()}
         Pf = {n: p.detach().clone().requires_grad_(True) for n, p in models["fine"].named_parameters()}
@@ -55,6 +55,22 @@ for it in range(steps):
             tot_dot, tot_a, tot_b = tot_dot + dot, tot_a + na * na, tot_b + nb * nb
             worst.append((1 - dot / (na * nb + 1e-300), float((a - b).norm() / (nb + 1e-300)), n))
         worst.sort(reverse=True)
+        # coherence of the error from one step to the next: cosine between e_t = g_hip - g_autograd at steps 50k and 50k+1
+        err = {n: (gh[n].double() - go[n].double()).flatten() for n in gh}
+        if it % 50 == 1:
+            coh = []
+            for n in err:
+                a, b = err[n], prev_err[n]
+                coh.append((float(a @ b / (a.norm() * b.norm() + 1e-300)), n))
+            coh.sort(reverse=True)
+            allc = torch.cat([err[n] for n in err]) @ torch.cat([prev_err[n] for n in err]) / (
+                torch.cat([err[n] for n in err]).norm() * torch.cat([prev_err[n] for n in err]).norm())
+            # a scale error shows as a component of e along g
+            along = float(torch.cat([err[n] for n in err]) @ torch.cat([go[n].double().flatten() for n in err])
+                          / torch.cat([go[n].double().flatten() for n in err]).norm() ** 2)
+            print(f"   error coherence steps {it - 1}->{it}: all tensors {float(allc):+.3f}; along-gradient component {along:+.2e}; most coherent: "
+                  + "; ".join(f"{n} {c:+.2f}" for c, n in coh[:4]) + " | least: " + "; ".join(f"{n} {c:+.2f}" for c, n in coh[-2:]), flush=True)
+        prev_err = err
         print(f"step {it:3d}: loss hip {float(loss):.6f} oracle {float(lo):.6f} rel {abs(float(loss) - float(lo)) / float(lo):.1e}; "
               f"grad cos deficit {1 - tot_dot / (tot_a * tot_b) ** 0.5:.2e}; worst tensors (1-cos, relL2): "
               + "; ".join(f"{n} {c:.1e} {e:.1e}" for c, e, n in worst[:3]), flush=True)
