@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFL_LIB") or os.path.join(_HERE, "libnerf_fl_amd.so")
 
-NFL_ABI_VERSION = 6
+NFL_ABI_VERSION = 7
 NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
@@ -130,6 +130,8 @@ SYMBOLS = [
     ("nfl_pack_field", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(FieldParams), C.c_void_p, C.c_size_t, C.c_void_p,
                                  C.c_void_p]),
     ("nfl_pack_fields", C.c_int, [C.c_int32, C.POINTER(PackJob), C.c_void_p]),
+    ("nfl_compose_forward", C.c_int, [C.POINTER(FieldParams), C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     ("nfl_render_pass", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(PassArgs), C.c_void_p]),
     ("nfl_sample_pdf", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_void_p]),

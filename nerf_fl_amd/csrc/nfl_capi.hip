@@ -103,7 +103,7 @@ int nfl_field_forward(const void* h_plan, const void* d_plan, const void* d_pack
 
 int nfl_abi_version(void) { return NFL_ABI_VERSION; }
 
-const char* nfl_version(void) { return "nerf_fl_amd 0.1 (gfx950, HIP; abi 6)"; }
+const char* nfl_version(void) { return "nerf_fl_amd 0.1 (gfx950, HIP; abi 7)"; }
 
 const char* nfl_strerror(int code) {
     switch (code) {

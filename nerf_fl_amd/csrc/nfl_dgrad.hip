@@ -529,31 +529,38 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         }
         K = nfl_dg_kargs();
         if (K->rays_tiles) dg_pe_tile<4, 0, 8, NCB>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
-        // d(feat) is not stashed: dW of xyz_encoding_final is composed from the 128-wide gradients it is a linear image of
-        if (K->use_t)
-            dg_tiles<WB, false, 8, 8, 8, 0, NCB, 16, false>(ring, moff, Q, 0, Q, 8, Q, 0, P, 0, gst, 0);
-        else if (K->has_t)      // the stream's d(feat) tiles carry the transient segment too: read the first 8 k-steps of 16
-            dg_tiles<WB, false, 8, 8, 0, 0, NCB, 16, false>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, 0);
-        else
-            dg_tiles<WB, false, 8, 8, 0, 0, NCB, 8, false>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, 0);
-        dg_tiles<WB, true, 8, 16, 1, 0, NCB>(ring, moff, P, 0, dS, 0, dS, 0, Q, 0, gst, NFL_GRD_D(8));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(7));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(6));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(5));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(4));
-        K = nfl_dg_kargs();
-        if (K->rays_tiles) {       // skip connection: delta_5 (still in P) reaches the encoded position too
-            dg_pe_tile<NFX, 0, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
+        // d(h8) straight from the 128-wide head gradients: xyz_encoding_final is folded into W_dir' / W_t0' (nfl_plan.cpp),
+        // so there are no d(feat) tiles; tile = [W_dir'^T: 8 k-steps | W_t0'^T: 8 (fields with a transient head) | W_sigma^T: 1]
+        if (K->use_t) {
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+        } else if (K->has_t) {      // the stream carries the transient segment: multiply it by zeros
+#pragma unroll
+            for (int ks = 8; ks < 16; ++ks)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) Q[ks][cb][0][j] = (_Float16)0.f;
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+        } else {
+            dg_tiles<WB, true, 8, 8, 1, 0, NCB>(ring, moff, Q, 0, dS, 0, dS, 0, P, 0, gst, NFL_GRD_D(8));
         }
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(3));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(2));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(1));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(7));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(6));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(5));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(4));
+        K = nfl_dg_kargs();
+        if (K->rays_tiles) {       // skip connection: delta_5 (still in Q) reaches the encoded position too
+            dg_pe_tile<NFX, 0, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+        }
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(3));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(2));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(1));
         if (K->rays_tiles) {
-            dg_pe_tile<NFX, 0, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, P, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 0, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
             if (K->a.d_g_rays) {
                 // x = o + d z ; the view direction is d itself (no caller passes view_dir with learnable poses)
 #pragma unroll

@@ -146,14 +146,11 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
                     [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR); });
     if (rays_grad)      // rows of W_dir^T that multiply the encoded view direction
         b.ttile(W, cd, -1, [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR); });
-    for (int t = 0; t < 8; ++t)
-        b.ttile(32 * t, 32, -1, [&](NflRowTile& r) {
-            Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR);
-            if (p->has_t) Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0);
-        }, t & 1);
+    // d(h8) = W_dir'^T d(dirh) (+ W_t0'^T d(g1)) + W_sigma^T d(sigma), W' the weights folded through xyz_encoding_final
     for (int t = 0; t < 8; ++t)
         b.ttile(32 * t, 32, nfl_msk_h(8) + t, [&](NflRowTile& r) {
-            Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_FINAL);
+            Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR);
+            if (p->has_t) Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0);
             Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_SIGMA);
         }, t & 1);
     const int npe = (cx + 31) / 32;         // 32-row tiles covering the encoded position
@@ -205,8 +202,9 @@ extern "C" int nfl_plan_fill(const nfl_field_desc* d, int prec, NflPlan* p) {
     b.layer(NFL_P_SIGMA, 1, 1, [&](NflRowTile& t) { Builder::seg(t, 16, NFL_SEG_ACT, 0, W); });
     p->n_rt_sigma = p->n_rt;
     p->n_chunks_sigma = p->n_chunks;
-    // static head
-    b.layer(NFL_P_FINAL, W, 1, [&](NflRowTile& t) { Builder::seg(t, 16, NFL_SEG_ACT, 0, W); });
+    // static head.  xyz_encoding_final is linear and feeds dir_encoding.0 / transient_encoding.0 only: it is folded into
+    // their first 256 input columns (W' = W[:, :256] W_fin, b' = b + W[:, :256] b_fin: nfl_compose_forward writes the
+    // folded copies the packer reads), so the stream has no tiles for it and both layers read h8 directly
     b.layer(NFL_P_DIR, H, 1, [&](NflRowTile& t) {
         Builder::seg(t, 16, NFL_SEG_ACT, 0, W);
         Builder::seg(t, 2, NFL_SEG_NAT, W, cd);

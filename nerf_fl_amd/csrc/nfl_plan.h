@@ -16,13 +16,13 @@
 //   L6..L8  8 row tiles each                                      X->Y->X->Y
 //   SIG     1 row tile (row 0 = static_sigma), K = Y              -> sigma
 //   ---- a sigma-only pass stops here ----
-//   FIN     8 row tiles (xyz_encoding_final, no activation), K=Y  -> X
-//   DIR     4 row tiles, K = X + D (dir PE 2 ks [+ appearance 3 ks]) -> Y[0:8], relu
-//   RGB     1 row tile (rows 0..2), K = Y[0:8]                    -> rgb
+//   (xyz_encoding_final has no tiles: linear, folded into the 256 columns of DIR / T1 that read its output)
+//   DIR     4 row tiles, K = Y + D (dir PE 2 ks [+ appearance 3 ks]) -> X[0:8], relu
+//   RGB     1 row tile (rows 0..2), K = X[0:8]                    -> rgb
 //   ---- a pass without the transient head stops here ----
-//   T1      4 row tiles, K = X + tau (1 ks)                       -> Y[0:8], relu
-//   T2..T4  4 row tiles each, K = 8 ks               Y[0:8]->Y[8:16]->Y[0:8]->Y[8:16]
-//   THEAD   1 row tile (row 0 sigma_t, 1..3 rgb_t, 8 beta), K = Y[8:16]
+//   T1      4 row tiles, K = Y + tau (1 ks)                       -> X[8:16], relu
+//   T2..T4  4 row tiles each, K = 8 ks               X[8:16]->X[0:8]->X[8:16]->X[0:8]
+//   THEAD   1 row tile (row 0 sigma_t, 1..3 rgb_t, 8 beta), K = X[0:8]
 //
 // Chunks (the unit of the LDS ring; every chunk starts a new barrier epoch):
 //   L1: 2 row tiles per chunk; T2..T4: 2 row tiles per chunk; otherwise 1.

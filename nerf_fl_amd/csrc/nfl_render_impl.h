@@ -876,9 +876,8 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         NFL_STAMP(9);
         K = nfl_kargs();           // head-side arguments (view directions, latents): loaded after the trunk
         if (!K->a.sigma_only) {
-            // final (linear).  Never stashed: the weight gradients that would read it are composed from
-            // G = sum_s delta_dirh (x) h8 instead (nfl_wgrad.hip: "composed through xyz_encoding_final")
-            nfl_dense<NP, NCB, 16, 0, false, 8, 1, false>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, 0, mst, 0);
+            // xyz_encoding_final has no tiles: it is linear and folded into the 256 columns of dir_encoding.0 /
+            // transient_encoding.0 that read its output (nfl_plan.cpp), so both read h8 (Y) directly and write into X
             NFL_STAMP(10);
             {
                 h8 D[5][NCB][NP];
@@ -939,14 +938,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 }
                 NFL_STAMP(11);
                 if (K->has_a)
-                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
+                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
                 else
-                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, D, 0, Y, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
+                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
             }
             NFL_STAMP(12);
             {
                 f16v hacc[NCB];
-                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 0, hacc);
+                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, X, 0, hacc);
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     o_rgb[cb][0] = hacc[cb][0];
@@ -977,12 +976,12 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     nfl_split8<NP>(v, T[0][cb]);
                     if (STASH) nfl_stash8(v, st[cb] + nfl_act_tau(NKP) * 1024);
                 }
-                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH>(ring, bias_lds, rt, h, X, 0, T, 0, Y, 0, st, nfl_act_g(NKP, 1), mst, nfl_msk_g(1));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 2), mst, nfl_msk_g(2));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 8, Y, 8, Y, 0, st, nfl_act_g(NKP, 3), mst, nfl_msk_g(3));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, Y, 8, st, nfl_act_g(NKP, 4), mst, nfl_msk_g(4));
+                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH>(ring, bias_lds, rt, h, Y, 0, T, 0, X, 8, st, nfl_act_g(NKP, 1), mst, nfl_msk_g(1));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 2), mst, nfl_msk_g(2));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, X, 8, st, nfl_act_g(NKP, 3), mst, nfl_msk_g(3));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 4), mst, nfl_msk_g(4));
                 f16v hacc[NCB];
-                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, Y, 8, hacc);
+                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, X, 0, hacc);
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll

@@ -321,6 +321,8 @@ struct WgGemm {
     const float* A2; int sam2, sak2;
     const float* B2; int sbk2, sbn2;
     const float* u; const float* v;       // rank-1 term (NULL: none)
+    const float* addm;                    // + addm[m] (NULL: none)
+    int avec, bvec;                       // the k-contiguous operand may be fetched with 16-byte loads (rows 16-byte aligned)
     float* Cp; int ldc;
     int M, N, K, K2;                      // K2 = 0: no second product
     int tiles_n, tile0;                   // tiles across N; index of this task's first workgroup
@@ -339,12 +341,12 @@ struct WgCompose {
 typedef float wg_f4 __attribute__((ext_vector_type(4)));
 template <int NJ>       // MFMAs per wave = (K / 4) / 2
 __device__ __forceinline__ void wg_compose_pass(f16v& acc, const float* A, int sam, int sak, const float* B, int sbk, int sbn,
-                                                int m, int n, bool n_ok, int k_wave, int h) {
+                                                int m, int n, bool n_ok, int k_wave, int h, bool avec, bool bvec) {
     float ra[NJ], rb[NJ];
 #pragma unroll
     for (int g = 0; g < NJ / 4; ++g) {
         const int kq = k_wave + 8 * g + 4 * h;
-        if (sak == 1) {
+        if (sak == 1 && avec) {
             const wg_f4 v = *reinterpret_cast<const wg_f4*>(A + (size_t)m * sam + kq);
             ra[4 * g] = v[0]; ra[4 * g + 1] = v[1]; ra[4 * g + 2] = v[2]; ra[4 * g + 3] = v[3];
         } else {
@@ -354,7 +356,7 @@ __device__ __forceinline__ void wg_compose_pass(f16v& acc, const float* A, int s
         if (!n_ok) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) rb[4 * g + e] = 0.f;
-        } else if (sbk == 1 && sbn != 1) {
+        } else if (sbk == 1 && sbn != 1 && bvec) {
             const wg_f4 v = *reinterpret_cast<const wg_f4*>(B + (size_t)n * sbn + kq);
             rb[4 * g] = v[0]; rb[4 * g + 1] = v[1]; rb[4 * g + 2] = v[2]; rb[4 * g + 3] = v[3];
         } else {
@@ -379,10 +381,10 @@ __global__ __launch_bounds__(256) void nfl_wgrad_compose_kernel(const WgCompose 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // K and K2 are 128 or 256 (host-checked): 32 or 64 per wave
-    if (T.K == 256) wg_compose_pass<32>(acc, T.A, T.sam, T.sak, T.B, T.sbk, T.sbn, m, n, n_ok, 64 * wave, h);
-    else wg_compose_pass<16>(acc, T.A, T.sam, T.sak, T.B, T.sbk, T.sbn, m, n, n_ok, 32 * wave, h);
-    if (T.K2 == 256) wg_compose_pass<32>(acc, T.A2, T.sam2, T.sak2, T.B2, T.sbk2, T.sbn2, m, n, n_ok, 64 * wave, h);
-    else if (T.K2 == 128) wg_compose_pass<16>(acc, T.A2, T.sam2, T.sak2, T.B2, T.sbk2, T.sbn2, m, n, n_ok, 32 * wave, h);
+    if (T.K == 256) wg_compose_pass<32>(acc, T.A, T.sam, T.sak, T.B, T.sbk, T.sbn, m, n, n_ok, 64 * wave, h, T.avec, T.bvec);
+    else wg_compose_pass<16>(acc, T.A, T.sam, T.sak, T.B, T.sbk, T.sbn, m, n, n_ok, 32 * wave, h, T.avec, T.bvec);
+    if (T.K2 == 256) wg_compose_pass<32>(acc, T.A2, T.sam2, T.sak2, T.B2, T.sbk2, T.sbn2, m, n, n_ok, 64 * wave, h, T.avec, T.bvec);
+    else if (T.K2 == 128) wg_compose_pass<16>(acc, T.A2, T.sam2, T.sak2, T.B2, T.sbk2, T.sbn2, m, n, n_ok, 32 * wave, h, T.avec, T.bvec);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(256) void nfl_wgrad_compose_kernel(const WgCompose 
         const int r = 4 * wave + q;                             // accumulator register r: row 8 (r / 4) + 4 h + (r % 4), column lane % 32
         const float c = red[0][r][lane] + red[1][r][lane] + red[2][r][lane] + red[3][r][lane];
         const int row = m0 + 8 * (r >> 2) + 4 * h + (r & 3);
-        if (n_ok) T.Cp[(size_t)row * T.ldc + n] = T.u ? __builtin_fmaf(T.u[row], T.v[n], c) : c;
+        if (n_ok) T.Cp[(size_t)row * T.ldc + n] = (T.u ? __builtin_fmaf(T.u[row], T.v[n], c) : c) + (T.addm ? T.addm[row] : 0.f);
     }
 }
 __global__ __launch_bounds__(256) void nfl_wgrad_scale_kernel(const WgTensors T, const int op, const float* gmax) {
@@ -639,6 +641,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     WgCompose Cc;
     memset(&Cc, 0, sizeof(Cc));
     auto add = [&](WgGemm g) {
+        g.avec = g.bvec = 1;                 // G and W_fin rows are 1 KiB: checked below
         g.tiles_n = (g.N + 31) / 32;
         g.tile0 = Cc.n_wg;
         Cc.n_wg += g.tiles_n * ((g.M + 31) / 32);
@@ -675,5 +678,45 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     }
     if (((uintptr_t)d_scratch | (uintptr_t)Wf) & 15) return NFL_EINVAL;      // float4 loads along k (G, W_fin rows)
     if (Cc.n_wg > 0) hipLaunchKernelGGL(nfl_wgrad_compose_kernel, dim3(Cc.n_wg), dim3(256), 0, s, Cc);
+    return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
+}
+
+// Fold xyz_encoding_final into the layers that read its output, for the PACKED streams only (the parameters stay what
+// they are): W_dir' = [W_dir[:, :256] W_fin | W_dir[:, 256:]], b_dir' = b_dir + W_dir[:, :256] b_fin, likewise for
+// transient_encoding.0.  The caller hands in copies of W_dir / W_t0 (the side columns are kept, the first 256 columns
+// overwritten) and receives the folded biases; nfl_pack_field(s) is then given these in place of the originals, and
+// the streams carry no tiles for xyz_encoding_final (nfl_plan.cpp): one 256 x 256 layer less in the forward and in dgrad.
+extern "C" int nfl_compose_forward(const nfl_field_params* params, int32_t has_t, int32_t n_a, int32_t n_tau,
+                                   float* d_wdir_c, float* d_bdir_c, float* d_wt0_c, float* d_bt0_c, void* stream) {
+    if (!params || !d_wdir_c || !d_bdir_c || (has_t && (!d_wt0_c || !d_bt0_c))) return NFL_EINVAL;
+    const float* Wf = params->weight[NFL_P_FINAL];
+    const float* bf = params->bias[NFL_P_FINAL];
+    if (!Wf || !bf || !params->weight[NFL_P_DIR] || !params->bias[NFL_P_DIR]) return NFL_EINVAL;
+    if (has_t && (!params->weight[NFL_P_T0] || !params->bias[NFL_P_T0])) return NFL_EINVAL;
+    const int W = NFL_W, H = NFL_W / 2;
+    WgCompose Cc;
+    memset(&Cc, 0, sizeof(Cc));
+    auto add = [&](WgGemm g) {
+        g.tiles_n = (g.N + 31) / 32;
+        g.tile0 = Cc.n_wg;
+        Cc.n_wg += g.tiles_n * ((g.M + 31) / 32);
+        Cc.t[Cc.n_tasks++] = g;
+    };
+    for (int which = 0; which < (has_t ? 2 : 1); ++which) {
+        const int L = which ? NFL_P_T0 : NFL_P_DIR;
+        const int ld = W + (which ? n_tau : 27 + n_a);
+        const float* Ws = params->weight[L];
+        WgGemm g;
+        memset(&g, 0, sizeof(g));          // W'[r, i] = sum_j W[r, j] W_fin[j, i]   (rows of W are not 16-byte aligned: scalar loads)
+        g.A = Ws; g.sam = ld; g.sak = 1; g.B = Wf; g.sbk = W; g.sbn = 1; g.K = W;
+        g.Cp = which ? d_wt0_c : d_wdir_c; g.ldc = ld; g.M = H; g.N = W;
+        add(g);
+        memset(&g, 0, sizeof(g));          // b'[r] = b[r] + sum_j W[r, j] b_fin[j]
+        g.A = Ws; g.sam = ld; g.sak = 1; g.B = bf; g.sbk = 1; g.sbn = 1; g.K = W;
+        g.addm = params->bias[L];
+        g.Cp = which ? d_bt0_c : d_bdir_c; g.ldc = 1; g.M = H; g.N = 1;
+        add(g);
+    }
+    hipLaunchKernelGGL(nfl_wgrad_compose_kernel, dim3(Cc.n_wg), dim3(256), 0, static_cast<hipStream_t>(stream), Cc);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

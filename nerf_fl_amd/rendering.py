@@ -160,6 +160,7 @@ class _PackedField:
         self.packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=device)
         self.key = None
         # dgrad stream (transposed weights, fp16, one product); built lazily on the first training forward
+        self.fold = None          # folded copies of dir_encoding.0 / transient_encoding.0 (weight, bias) for the packer
         self.bplans = {}          # rays_grad -> dict(h, d, packed, nbytes, key)
         self.wplans = {}          # use_transient -> (host blob, device copy) of the wgrad job list
 
@@ -199,7 +200,7 @@ class _PackedField:
         L = _lib.lib()
         bp = self.bwd_plan(rays_grad)
         if bp["key"] != self.key:
-            fp, _keep = self._field_params()
+            fp, _keep = self._pack_params()
             _lib.check(L.nfl_pack_field(bp["h"], _ptr(bp["d"]), C.byref(fp), _ptr(bp["packed"]), bp["nbytes"],
                                         C.c_void_p(0), _stream()), "nfl_pack_field(bwd)")
             bp["key"] = self.key
@@ -221,6 +222,29 @@ class _PackedField:
             fp.bias[i] = b.data_ptr()
         return fp, keep
 
+    def _pack_params(self):
+        """The parameters as the PACKED streams see them: xyz_encoding_final folded into the first 256 input columns of
+        dir_encoding.0 / transient_encoding.0 (include/nerf_fl_amd.h: nfl_compose_forward).  One launch + two (four) small
+        copies per re-pack; the gradients still go to the original parameters (nfl_mlp_wgrad composes them)."""
+        fp, keep = self._field_params()
+        params = dict(self.model_ref().named_parameters())
+        has_t = "transient_encoding.0.weight" in params
+        names = ["dir_encoding.0"] + (["transient_encoding.0"] if has_t else [])
+        if self.fold is None:
+            self.fold = {n: (torch.empty_like(params[n + ".weight"], dtype=torch.float32).contiguous(),
+                             torch.empty_like(params[n + ".bias"], dtype=torch.float32).contiguous()) for n in names}
+        for n in names:
+            self.fold[n][0].copy_(params[n + ".weight"].detach())        # the side columns ride along; the first 256 are overwritten
+        wd, bd = self.fold["dir_encoding.0"]
+        wt, bt = self.fold["transient_encoding.0"] if has_t else (None, None)
+        _lib.check(_lib.lib().nfl_compose_forward(C.byref(fp), int(has_t), int(self.desc.n_a if self.desc.encode_appearance else 0),
+                                                  int(self.desc.n_tau), _ptr(wd), _ptr(bd), _ptr(wt), _ptr(bt), _stream()),
+                   "nfl_compose_forward")
+        for n in names:
+            i = _lib.LAYER_NAMES.index(n)
+            fp.weight[i], fp.bias[i] = self.fold[n][0].data_ptr(), self.fold[n][1].data_ptr()
+        return fp, keep
+
     def current_key(self):
         return tuple((n, p.data_ptr(), p._version) for n, p in self.model_ref().named_parameters())
 
@@ -228,7 +252,7 @@ class _PackedField:
         key = self.current_key()
         if key == self.key:
             return
-        fp, _keep = self._field_params()
+        fp, _keep = self._pack_params()
         _lib.check(_lib.lib().nfl_pack_field(self.h_plan, _ptr(self.d_plan), C.byref(fp), _ptr(self.packed),
                                              self.packed_bytes, _ptr(_status_word(self.device)), _stream()),
                    "nfl_pack_field")
@@ -265,7 +289,7 @@ def _pack_streams(fields, bwd, rays_grad):
         stale_bwd = bp is not None and bp["key"] != key
         if not (stale_fwd or stale_bwd):
             continue
-        fp, tensors = f._field_params()
+        fp, tensors = f._pack_params()
         keep += [fp, tensors]
         if stale_fwd:
             jobs.append((f, None, key, _lib.PackJob(C.cast(f.h_plan, C.c_void_p), _ptr(f.d_plan), C.pointer(fp), _ptr(f.packed),

@@ -57,12 +57,12 @@ def test_plan_structure(L):
     assert magic == 0x4E464C31 and nsplit == 3 and nx == 10 and nkp == 4 and has_a == 1 and has_t == 1
     assert elem == 0 and is_bwd == 0 and flags == 0
     n_rt, n_rt_sigma, n_rt_static, n_chunks, n_chunks_sigma, n_chunks_static, total_ks, ks_bytes = hdr[12:20]
-    assert (n_rt_sigma, n_rt_static, n_rt) == (65, 78, 95)
-    assert (n_chunks_sigma, n_chunks_static, n_chunks) == (61, 74, 85)
+    assert (n_rt_sigma, n_rt_static, n_rt) == (65, 70, 87)          # no tiles for xyz_encoding_final: folded into dir / transient layer 0
+    assert (n_chunks_sigma, n_chunks_static, n_chunks) == (61, 66, 77)
     assert ks_bytes == 2048
-    # k-steps: L1 8x4, six 256x256 layers 8x16, skip layer 8x20, sigma 16, final 8x16, dir 4x21, rgb 8,
+    # k-steps: L1 8x4, six 256x256 layers 8x16, skip layer 8x20, sigma 16, dir 4x21, rgb 8,
     # transient 4x17 + 3x(4x8) + 8
-    assert total_ks == 32 + 6 * 128 + 160 + 16 + 128 + 84 + 8 + 68 + 96 + 8
+    assert total_ks == 32 + 6 * 128 + 160 + 16 + 84 + 8 + 68 + 96 + 8
     assert L.nfl_packed_bytes(C.byref(d), _lib.NFL_PREC_F16X3) == total_ks * 2048 + n_rt * 128
     assert L.nfl_packed_bytes(C.byref(d), _lib.NFL_PREC_F16) == total_ks * 1024 + n_rt * 128
 
@@ -76,12 +76,12 @@ def test_bwd_plan_structure(L):
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
     assert hdr[1] == 1 and hdr[2] == 1 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == 0     # fp16 single-product fragments, dgrad stream, no rays-gradient tiles
     n_rt, n_chunks, total_ks = hdr[12], hdr[15], hdr[18]
-    # transposed row tiles: transient 4+12+1, rgb^T 4, appearance rows 2, feat 8, h8 8, 7 trunk layers x 8; the tiles of
+    # transposed row tiles: transient 4+12+1, rgb^T 4, appearance rows 2, h8 8 (dir' | t0' | sigma), 7 trunk layers x 8; the tiles of
     # the 4- and 8-tile groups travel two per chunk, the latent rows one per chunk
-    assert n_rt == 17 + 4 + 2 + 8 + 8 + 56
-    assert n_chunks == (2 + 6 + 1) + 2 + 2 + 4 + 4 + 28
+    assert n_rt == 17 + 4 + 2 + 8 + 56
+    assert n_chunks == (2 + 6 + 1) + 2 + 2 + 4 + 28
     assert hdr[16] == 9                                     # first chunk of the non-transient part (n_chunks_sigma re-used)
-    assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 16 + 8 * 17 + 56 * 16
+    assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 17 + 56 * 16
     assert L.nfl_bwd_packed_bytes(C.byref(d), 0) == total_ks * 1024 + n_rt * 128
     # with the gradient w.r.t. the rays: + direction rows (1 tile, 8 ks) + encoded-position rows of layers 5 and 1 (2 x 2 tiles, 16 ks)
     assert L.nfl_bwd_plan_build(C.byref(d), 1, buf, n) == 0
