@@ -22,6 +22,7 @@ python3 bench.py > "$OUT/bench_train.json" 2> "$OUT/bench_train.err"
 python3 bench.py --mode render --no-cpu-baseline > "$OUT/bench_render.json" 2> "$OUT/bench_render.err"
 python3 tests/time_passes.py > "$OUT/time_passes.txt" 2>&1
 python3 tests/bench_configs.py > "$OUT/bench_configs.json" 2> "$OUT/bench_configs.err"
-python3 bench.py --no-extras --workload cfg3 --rays 1024 --steps 40 --warmup 10 > "$OUT/bench_cfg3_r1024.json" 2>/dev/null
 python3 bench.py --no-extras --workload cfg3 --rays 4096 --steps 20 --warmup 5 > "$OUT/bench_cfg3_r4096.json" 2>/dev/null
+python3 bench.py --no-extras --workload cfg3 --rays 1024 --steps 100 --warmup 10 --graph > "$OUT/bench_cfg3_r1024_graph.json" 2>/dev/null
+python3 bench.py --no-extras --workload cfg3 --rays 1024 --steps 100 --warmup 10 > "$OUT/bench_cfg3_r1024.json" 2>/dev/null
 find "$OUT" -name "*.csv" | head -20

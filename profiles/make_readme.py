@@ -13,6 +13,7 @@ s = json.load(open(os.path.join(here, f"{tag}_summary.json")))
 cl, st, tr, sq = s["launch_clusters"], s["step_traffic"], s["traffic"], s["sq"]
 g = lambda k: round(cl[k]["avg_us"] / 1e3, 3)
 bt, br, c1, c4 = J("bench_train"), J("bench_render"), J("bench_cfg3_r1024"), J("bench_cfg3_r4096")
+c1g = J("bench_cfg3_r1024_graph")
 bc = json.load(open(os.path.join(here, f"{tag}_bench_configs.json")))
 K0, K1 = "nfl_render_kernel<3, 1, 10, 0>", "nfl_render_kernel<3, 1, 10, 1>"
 F0, F1 = K0 + "|fine_pass_128_samples", K1 + "|fine_pass_128_samples"
@@ -43,12 +44,15 @@ section 5) and the sigma head's job merged into the G job's `h8` stream. Same-bo
 (`git worktree` of the previous commit built side by side): training forward 1.717 -> 1.695 ms, dgrad 0.695 -> 0.669,
 wgrad 1.050 -> 0.944, train step **5.21 -> 4.98 ms**; configs[3] shape 6.02 -> 5.91 ms (4096 rays), 1.94 -> 1.85 ms (1024);
 HBM bytes per step 18.3 -> 16.4 GB.
+Last, the layer left the forward and dgrad streams altogether (folded into the two layers that read it at pack time,
+DESIGN.md section 3): forward 1.52 -> 1.37 ms per fine pass, training forward 1.69 -> 1.52, dgrad 0.67 -> 0.63, train step
+4.95 -> 4.66 ms, with the same worst parity error (1.29e-5).
 
 | file | what |
 |---|---|
-| `{tag}_bench_train.json` | `python bench.py` (default = train step): **{bt["value"]:.3e} ray-samples/s**, {bt["ms_per_step"]:.2f} ms/step on this box (4.89-5.25 across the boxes seen since the composed backward); forward-only {bt["render_only_value"]:.2e}; CPU oracle train step {bt["cpu_baseline"]["value"]:.2e} (16 threads; forward alone {bt["cpu_baseline"]["forward_value"]:.2e}) |
+| `{tag}_bench_train.json` | `python bench.py` (default = train step): **{bt["value"]:.3e} ray-samples/s**, {bt["ms_per_step"]:.2f} ms/step on this box (4.6-4.8 across the boxes seen since the layer was folded); forward-only {bt["render_only_value"]:.2e}; CPU oracle train step {bt["cpu_baseline"]["value"]:.2e} (16 threads; forward alone {bt["cpu_baseline"]["forward_value"]:.2e}) |
 | `{tag}_bench_render.json` | `python bench.py --mode render`: **{br["value"]:.3e} ray-samples/s**, {br["ms_per_step"]:.2f} ms/step |
-| `{tag}_bench_cfg3_r1024.json`, `{tag}_bench_cfg3_r4096.json` | `--workload cfg3` (configs[3] per-GPU shape: NeRF-W a+t, N_vocab 1500, per-ray near/far): {c1["ms_per_step"]:.2f} ms/step = {c1["value"]:.2e} at the README batch of 1024 rays (1.85 ms same-box against 1.94 for the previous backward layout), {c4["ms_per_step"]:.2f} ms = {c4["value"]:.2e} at 4096; the same from one HIP graph (`--graph`) measured side by side before the backward change: 1.931 vs 1.934 ms and 5.44 vs 5.44 ms |
+| `{tag}_bench_cfg3_r1024.json`, `{tag}_bench_cfg3_r1024_graph.json`, `{tag}_bench_cfg3_r4096.json` | `--workload cfg3` (configs[3] per-GPU shape: NeRF-W a+t, N_vocab 1500, per-ray near/far): at the README batch of 1024 rays {c1["ms_per_step"]:.2f} ms/step eager and **{c1g["ms_per_step"]:.2f} ms = {c1g["value"]:.2e}** replayed from one HIP graph (`--graph`) — with the device side down to ~1.6 ms the ~35 launches of an eager step have become the critical path at this batch size (they were not before the backward and forward cuts of this round: 1.931 vs 1.934 ms); {c4["ms_per_step"]:.2f} ms = {c4["value"]:.2e} at 4096 rays, where eager and graph are equal |
 | `{tag}_bench_configs.json` | `tests/bench_configs.py`: configs[2] full NeRF-W train step {bc["cfg3_nerfw_train"]["ms_per_step"]:.2f} ms = {bc["cfg3_nerfw_train"]["ray_samples_per_s"]:.2e}; configs[4]-like eval (NeRF-W, 128+128, `test_time`, 131072 rays) {bc["cfg5_eval_direct"]["ms_per_131072_rays"]:.0f} ms = {bc["cfg5_eval_direct"]["rays_per_s"]:.2e} rays/s direct, {bc["cfg5_eval_hip_graph"]["ms_per_131072_rays"]:.0f} ms HIP-graph replayed; one 800 x 800 frame from (pose, intrinsics) {bc["cfg5_frame_800x800_camera_prologue"]["ms_per_frame"]:.0f} ms with the rays generated in the kernel prologue, {bc["cfg5_frame_800x800_ray_matrix"]["ms_per_frame"]:.0f} ms from a materialised ray matrix (the 21 MB of rays were never the cost) |
 | `{tag}_train_step_kernel_stats.csv` | per-kernel time of the profiled command |
 | `{tag}_train_step_pmc_{{FETCH_SIZE,WRITE_SIZE,SQ}}.csv` | PMC passes (nfl_* kernels) |
@@ -64,7 +68,7 @@ Per launch, fine pass (4096 rays x 128 samples), this box:
 | kernel | time | bound | achieved | MFMA pipe busy (PMC) | HBM bytes (PMC) |
 |---|---|---|---|---|---|
 | `{K0}` (inference forward) | {g(F0)} ms | mfma | {0.622e12/cl[F0]["avg_us"]/1e6:.0f} TFLOP/s algorithmic = frac {frac(F0):.3f} of 2.5 PFLOP/s (3 fp16 products issued per algorithmic product) | {100*sq[K0]["mfma_busy_frac"]:.1f} % | {tr[K0]["hbm_bytes_max_launch"]/1e6:.0f} MB (algorithmic ~7 MB) |
-| `{K1}` (training forward: + fp16 stash + relu-mask words + loss epilogue) | {g(F1)} ms | mfma | frac {frac(F1):.3f} | {100*sq[K1]["mfma_busy_frac"]:.1f} % | {tr[K1]["hbm_bytes_max_launch"]/1e9:.2f} GB (stash write 2.6 GB) |
+| `{K1}` (training forward: + fp16 stash + relu-mask words + loss epilogue) | {g(F1)} ms | mfma | frac {frac(F1):.3f} | {100*sq[K1]["mfma_busy_frac"]:.1f} % | {tr[K1]["hbm_bytes_max_launch"]/1e9:.2f} GB (stash write 2.7 GB) |
 | `nfl_dgrad_kernel<10>` | {g("nfl_dgrad_kernel<10>|fine_pass_128_samples")} ms | hbm (stash write) | {tr["nfl_dgrad_kernel<10>"]["hbm_bytes_max_launch"]/cl["nfl_dgrad_kernel<10>|fine_pass_128_samples"]["avg_us"]/1e6:.2f} TB/s | {100*sq["nfl_dgrad_kernel<10>"]["mfma_busy_frac"]:.1f} % | {tr["nfl_dgrad_kernel<10>"]["hbm_bytes_max_launch"]/1e9:.2f} GB |
 | `nfl_wgrad_kernel` | {g("nfl_wgrad_kernel|fine_pass_128_samples")} ms | hbm | {tr["nfl_wgrad_kernel"]["hbm_bytes_max_launch"]/cl["nfl_wgrad_kernel|fine_pass_128_samples"]["avg_us"]/1e6:.2f} TB/s of 8 TB/s | {100*sq["nfl_wgrad_kernel"]["mfma_busy_frac"]:.1f} % | {tr["nfl_wgrad_kernel"]["hbm_bytes_max_launch"]/1e9:.2f} GB |
 | `nfl_compbwd_kernel` / `nfl_sample_pdf_kernel` / `nfl_pack_kernel` / `nfl_adam_kernel` | 14 / 16 / 8 / 17 us | hbm | — | — | 46 / 5 / 8 / 33 MB |

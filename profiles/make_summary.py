@@ -119,7 +119,7 @@ step_traffic = {"hbm_bytes": (2.0 * tot_f + tot_w) * 1024.0 / n_steps, "steps_co
 json.dump({"kernel_stats": kernel_stats, "launch_clusters": clusters, "traffic": traffic, "sq": sqs, "step_traffic": step_traffic},
           open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1)
 for f in ("bench_train.json", "bench_render.json", "time_passes.txt", "bench_configs.json", "bench_cfg3_r1024.json",
-          "bench_cfg3_r4096.json"):
+          "bench_cfg3_r4096.json", "bench_cfg3_r1024_graph.json"):
     p = os.path.join(src, f)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(here, f"{tag}_{f}"))
