@@ -136,6 +136,9 @@ def test_auxiliary_entry_points_validate_arguments(L):
     assert L.nfl_wgrad_scratch_bytes() == 256 * 256 * 4
     assert L.nfl_pack_fields(0, None, None) == 0                                            # nothing to do
     assert L.nfl_pack_fields(1, None, None) == -1 and L.nfl_pack_fields(_lib.NFL_PACK_MAX_JOBS + 1, None, None) == -1
+    assert L.nfl_compose_forward(None, 0, 0, 16, None, None, None, None, None) == -1        # no parameters
+    fp = _lib.FieldParams()
+    assert L.nfl_compose_forward(C.byref(fp), 0, 0, 16, C.c_void_p(16), C.c_void_p(16), None, None, None) == -1   # xyz_encoding_final missing
     job = (_lib.PackJob * 1)()                                                              # a job without a plan
     assert L.nfl_pack_fields(1, job, None) == -1
 
