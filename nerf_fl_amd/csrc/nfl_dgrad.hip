@@ -496,8 +496,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             }
         }
         // Two operand sets of 16 k-steps are enough for the whole walk: the transient chain ping-pongs between
-        // the halves of Q, d(dir hidden) lands in Q[0..8) next to dg1 in Q[8..16), d(feat) in P, then the trunk
-        // alternates Q, P, Q, ...
+        // the halves of Q, d(dir hidden) lands in Q[0..8) next to dg1 in Q[8..16), d(h8) -- straight from those two through
+        // the folded W_dir' / W_t0' -- in P, then the trunk alternates Q, P, Q, ...
         h8 P[16][NCB][1], Q[16][NCB][1];
         K = nfl_dg_kargs();
         if (K->use_t) {
