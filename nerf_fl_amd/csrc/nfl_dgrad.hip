@@ -199,7 +199,7 @@ NFL_DEV void dg_zero(f16v (&acc)[NCB]) {
 
 // epilogue of a dgrad tile, cut into 8 pair-ops: relu mask (sign of the stashed activation),
 // fp16 into the next operand set and into the gradient stash
-template <bool MASK, int NOUT, int NCB, bool STORE = true>
+template <bool MASK, int NOUT, int NCB>
 struct DgEpi {
     const f16v (&acc)[NCB];
     const unsigned (&mk)[NCB];
@@ -232,15 +232,11 @@ struct DgEpi {
 #ifdef DG_ABL_NOSTORE
             if (false) {
 #else
-            if (STORE && OP == 7) {
+            if (OP == 7) {
 #endif
                 // streaming stores: the 2.6 GB of stash must not evict the weight stream from L2
                 __builtin_nontemporal_store(out[ks][cb][0], reinterpret_cast<h8*>(gst[cb] + slot * 1024));
                 __builtin_nontemporal_store(out[ks + 1][cb][0], reinterpret_cast<h8*>(gst[cb] + (slot + 1) * 1024));
-            } else if (!STORE && OP == 7) {
-                // keep the two operand images complete at the point where the store would have read them: without this
-                // anchor hipcc reorders the epilogue of the unstored tiles and spills (scratch 0 -> 528 B/lane)
-                asm volatile("" :: "v"(out[ks][cb][0]), "v"(out[ks + 1][cb][0]));
             }
         }
     }
@@ -261,8 +257,7 @@ struct DgEpi {
 
 // NRT transposed row tiles (two per chunk) with up to three K segments.  TS: k-steps a tile occupies in the stream
 // (more than the NK it reads when a pass leaves out the transient head's segment of the d(feat) tiles)
-// STORE = false: the tiles' gradients stay in registers only (d(feat): no weight-gradient job reads them, nfl_wgrad.hip)
-template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int TS = NKA + NKB + NKC, bool STORE = true, int NA, int NB, int NC, int NOUT, class Ring>
+template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int TS = NKA + NKB + NKC, int NA, int NB, int NC, int NOUT, class Ring>
 NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
                       const h8 (&inA)[NA][NCB][1], int ksA, const h8 (&inB)[NB][NCB][1], int ksB,
                       const h8 (&inC)[NC][NCB][1], int ksC,
@@ -297,9 +292,9 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
             for (int cb = 0; cb < NCB; ++cb) mk[i & 1][cb] = mkq[cb][i & 3];
         }
         if constexpr (i > 0) {
-            DgEpi<MASK, NOUT, NCB, STORE> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
+            DgEpi<MASK, NOUT, NCB> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
             nfl_tile<1, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
-            if (STORE) ring.note(2 * NCB);          // the epilogue's stash stores, issued at the tile's last k-step
+            ring.note(2 * NCB);          // the epilogue's stash stores, issued at the tile's last k-step
         } else {
             NflNoEpi epi;
             nfl_tile<1, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
@@ -308,9 +303,9 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         if constexpr ((i & 1) == 0) ring.template pieces<NK, TS>();
         else ring.template pieces<TS + NK, Ring::MAXP>();
     });
-    DgEpi<MASK, NOUT, NCB, STORE> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
+    DgEpi<MASK, NOUT, NCB> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
     last.all();
-    if (STORE) ring.note(2 * NCB);
+    ring.note(2 * NCB);
 }
 
 // one tile whose rows are latent inputs: sum over the 32 samples of each segment, add to its ray's gradient
