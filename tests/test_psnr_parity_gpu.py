@@ -84,25 +84,23 @@ def test_fit_psnr_matches_oracle():
 # plus three standard errors of that difference.  Measured: base 22.05 (HIP, 27 runs) vs 22.00 dB (reference, 6 runs).
 #
 # Training loss, windowed over 50 steps.  Over the first 100 steps the HIP curve is the reference's (2e-4 per 10-step
-# window, 1e-6 per step: tests/report_psnr_curve.py).  Later the HIP curve drifts BELOW the reference's, in every launch
-# and gradually: -1.5 % around step 300, -3 % around 400, -4 .. -6 % in the last windows (base scene; < 1 % on NeRF-W),
-# where the reference's own replicas stay within 1 % of each other.  This is not an error of the kernels -- along a HIP
-# trajectory the loss equals the fp32 forward's to 1e-7 and the gradient's cosine with fp32 autograd is 1 - 1e-8, worst
-# tensor 4e-3 relative (tests/report_psnr_fwdcheck.py) -- and not the optimizer (the fp32 oracle trained ON THE GPU follows
-# the CPU reference to 0.5 % with torch's Adam and to 0.2 % with this package's, tests/report_psnr_oracle_gpu.py).  What
-# does reproduce it in that fp32 oracle is an additive gradient error of the size the fp16 backward has (2-4e-4 of a
-# tensor's norm per step, white over its elements): one FIXED noise pattern of 3e-4 of each tensor's norm added at every
-# step drifts the same way in three of three runs (-3 % at step 400, -5.9 / -6.7 / -6.7 % in the last window); fresh white
-# noise of that size does so on average but not every time (-5.1 .. +0.5 % over seven runs); a multiplicative perturbation
-# does not (+-2 %).  Emulating the backward's single rounding sites in autograd (fp16 weights in the input-gradient
-# products, fp16 activations and loss-scaled fp16 gradients in the weight-gradient products, the fp16 gradient chain)
-# gives -1.6 .. +1.5 %, i.e. no single site accounts for all of it.  The HIP error itself is fresh at every step (cosine
-# between the errors of consecutive steps -0.2 .. +0.1 over all tensors, tests/report_psnr_fwdcheck.py), so it is the
-# "fresh noise" case, at its strong end: continual gradient noise shifts the late training loss of this scene down by
-# 0 .. 7 %, a one-time perturbation (the reference's replicas) does not.  (A much larger floor, 1e-3 of max|g| per element,
-# hurts: +8 % loss, -0.3 dB, on the GPU and in the reference itself, psnr_base_gradnoise*.npz.)
-# profiles/r02_psnr_drift_control.txt holds these runs.  The validation PSNR does not move with the drift.  The test pins
-# the first 100 steps tightly (0.5 %) and allows 8 % on the mean curve later.
+# window, 1e-6 per step: tests/report_psnr_curve.py); later it scatters around it like the reference's own replicas do:
+# base scene -2.4 .. +0.9 % per run in the last window (mean of 8 runs -0.6 %; the replicas' sigma there is 1.3 %),
+# NeRF-W -0.4 % (mid-run -1 %).  The test pins the first 100 steps at 0.5 % and allows 4 % on the mean curve later.
+#
+# History worth keeping.  Until xyz_encoding_final was folded out of the packed streams the HIP curve
+# of the base scene drifted BELOW the reference's in every launch, gradually: -1.5 % around step 300, -3 % around 400,
+# -4 .. -7 % in the last windows, with validation PSNR unaffected.  The hunt (profiles/r02_psnr_drift_control.txt) excluded
+# the forward (loss equal to the fp32 forward's to 1e-7 along a HIP trajectory), the gradients' accuracy (cosine with fp32
+# autograd 1 - 1e-8, worst tensor 4e-3 relative, errors uncorrelated from step to step: tests/report_psnr_fwdcheck.py),
+# the optimizer and the harness (the fp32 oracle trained ON THE GPU follows the CPU reference to 0.5 % with torch's Adam,
+# 0.2 % with this package's: tests/report_psnr_oracle_gpu.py), showed that additive gradient noise of the backward's size
+# produces such a drift in fp32 autograd (a fixed pattern of 3e-4 of each tensor's norm: -5.9 / -6.7 / -6.7 %; fresh white
+# noise: -5.1 .. +0.5 %; multiplicative noise or emulated fp16 roundings of single sites: +-2 %), and ended when the layer
+# left the dgrad stream: with d(h8) computed from the 128-wide head gradients through ONE fp16 matrix (W_dir' = W_dir
+# W_fin) instead of two in a row with an fp16 intermediate and no relu mask between them, the drift is gone while the
+# per-step gradient errors are the size they were.  What exactly in that two-product path biased the trunk's gradients
+# coherently enough for Adam to integrate it was not isolated.
 N_HIP_RUNS = 4
 
 
@@ -200,4 +198,4 @@ def test_fit_psnr_matches_reference_64_64(kind):
     assert abs(hip_psnr.mean() - ref_psnr.mean()) <= 0.1 + 3.0 * se
     assert np.abs(hip_psnr - ref_psnr.mean()).max() <= 0.1 + 5.0 * max(s_ref, s_hip), "a single run far outside the scatter"
     assert np.abs(dev_rel[:2]).max() <= 0.005, "the first 100 steps follow the reference's curve"
-    assert np.abs(dev_rel).max() <= 0.08
+    assert np.abs(dev_rel).max() <= 0.04
