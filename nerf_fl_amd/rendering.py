@@ -160,9 +160,20 @@ class _PackedField:
         self.packed = torch.empty(self.packed_bytes, dtype=torch.uint8, device=device)
         self.key = None
         # dgrad stream (transposed weights, fp16, one product); built lazily on the first training forward
+        self._slots = None        # (submodule, parameter slot, qualified name) of every parameter: _named()
         self.fold = None          # folded copies of dir_encoding.0 / transient_encoding.0 (weight, bias) for the packer
         self.bplans = {}          # rays_grad -> dict(h, d, packed, nbytes, key)
         self.wplans = {}          # use_transient -> (host blob, device copy) of the wgrad job list
+
+    def _named(self):
+        """name -> nn.Parameter, as dict(model.named_parameters()) but without walking the module tree on every call (73 us
+        per walk, ten walks per training step: at the README batch of 1024 rays that was a quarter of the eager step's host
+        time).  The (submodule, slot) pairs are collected once; the Parameter objects are read through them, so a
+        parameter that is re-assigned is still seen."""
+        if self._slots is None:
+            self._slots = [(mod, pn, (prefix + "." if prefix else "") + pn)
+                           for prefix, mod in self.model_ref().named_modules() for pn in mod._parameters]
+        return {q: mod._parameters[pn] for mod, pn, q in self._slots if mod._parameters[pn] is not None}
 
     def wgrad_plan(self, use_t):
         if use_t not in self.wplans:
@@ -175,7 +186,7 @@ class _PackedField:
 
     def param_list(self):
         """(layer index, weight, bias) for every layer this field has, in NFL_P_* order."""
-        params = dict(self.model_ref().named_parameters())
+        params = self._named()
         out = []
         for i, name in enumerate(_lib.LAYER_NAMES):
             if name + ".weight" in params:
@@ -207,7 +218,7 @@ class _PackedField:
         return bp
 
     def _field_params(self):
-        params = dict(self.model_ref().named_parameters())
+        params = self._named()
         fp = _lib.FieldParams()
         keep = []
         for i, name in enumerate(_lib.LAYER_NAMES):
@@ -227,7 +238,7 @@ class _PackedField:
         dir_encoding.0 / transient_encoding.0 (include/nerf_fl_amd.h: nfl_compose_forward).  One launch + two (four) small
         copies per re-pack; the gradients still go to the original parameters (nfl_mlp_wgrad composes them)."""
         fp, keep = self._field_params()
-        params = dict(self.model_ref().named_parameters())
+        params = self._named()
         has_t = "transient_encoding.0.weight" in params
         names = ["dir_encoding.0"] + (["transient_encoding.0"] if has_t else [])
         if self.fold is None:
@@ -246,7 +257,7 @@ class _PackedField:
         return fp, keep
 
     def current_key(self):
-        return tuple((n, p.data_ptr(), p._version) for n, p in self.model_ref().named_parameters())
+        return tuple((n, p.data_ptr(), p._version) for n, p in self._named().items())
 
     def ensure_packed(self):
         key = self.current_key()

@@ -52,7 +52,7 @@ DESIGN.md section 3): forward 1.52 -> 1.37 ms per fine pass, training forward 1.
 |---|---|
 | `{tag}_bench_train.json` | `python bench.py` (default = train step): **{bt["value"]:.3e} ray-samples/s**, {bt["ms_per_step"]:.2f} ms/step on this box (4.6-4.8 across the boxes seen since the layer was folded); forward-only {bt["render_only_value"]:.2e}; CPU oracle train step {bt["cpu_baseline"]["value"]:.2e} (16 threads; forward alone {bt["cpu_baseline"]["forward_value"]:.2e}) |
 | `{tag}_bench_render.json` | `python bench.py --mode render`: **{br["value"]:.3e} ray-samples/s**, {br["ms_per_step"]:.2f} ms/step |
-| `{tag}_bench_cfg3_r1024.json`, `{tag}_bench_cfg3_r1024_graph.json`, `{tag}_bench_cfg3_r4096.json` | `--workload cfg3` (configs[3] per-GPU shape: NeRF-W a+t, N_vocab 1500, per-ray near/far): at the README batch of 1024 rays {c1["ms_per_step"]:.2f} ms/step eager and **{c1g["ms_per_step"]:.2f} ms = {c1g["value"]:.2e}** replayed from one HIP graph (`--graph`) — with the device side down to ~1.6 ms the ~35 launches of an eager step have become the critical path at this batch size (they were not before the backward and forward cuts of this round: 1.931 vs 1.934 ms); {c4["ms_per_step"]:.2f} ms = {c4["value"]:.2e} at 4096 rays, where eager and graph are equal |
+| `{tag}_bench_cfg3_r1024.json`, `{tag}_bench_cfg3_r1024_graph.json`, `{tag}_bench_cfg3_r4096.json` | `--workload cfg3` (configs[3] per-GPU shape: NeRF-W a+t, N_vocab 1500, per-ray near/far): at the README batch of 1024 rays **{c1["ms_per_step"]:.2f} ms/step = {c1["value"]:.2e}** eager, {c1g["ms_per_step"]:.2f} ms replayed from one HIP graph (`--graph`); the eager step had stayed at 1.87-1.95 ms when the device side came down to ~1.6 ms, until ten module-tree walks per step (0.7 ms of host time) were removed; {c4["ms_per_step"]:.2f} ms = {c4["value"]:.2e} at 4096 rays, where eager and graph are equal |
 | `{tag}_bench_configs.json` | `tests/bench_configs.py`: configs[2] full NeRF-W train step {bc["cfg3_nerfw_train"]["ms_per_step"]:.2f} ms = {bc["cfg3_nerfw_train"]["ray_samples_per_s"]:.2e}; configs[4]-like eval (NeRF-W, 128+128, `test_time`, 131072 rays) {bc["cfg5_eval_direct"]["ms_per_131072_rays"]:.0f} ms = {bc["cfg5_eval_direct"]["rays_per_s"]:.2e} rays/s direct, {bc["cfg5_eval_hip_graph"]["ms_per_131072_rays"]:.0f} ms HIP-graph replayed; one 800 x 800 frame from (pose, intrinsics) {bc["cfg5_frame_800x800_camera_prologue"]["ms_per_frame"]:.0f} ms with the rays generated in the kernel prologue, {bc["cfg5_frame_800x800_ray_matrix"]["ms_per_frame"]:.0f} ms from a materialised ray matrix (the 21 MB of rays were never the cost) |
 | `{tag}_train_step_kernel_stats.csv` | per-kernel time of the profiled command |
 | `{tag}_train_step_pmc_{{FETCH_SIZE,WRITE_SIZE,SQ}}.csv` | PMC passes (nfl_* kernels) |
