@@ -42,7 +42,13 @@ N_SAMPLES, N_IMPORTANCE = 64, 64
 FLOP_EVAL = {"base": 2 * 593408, "at": 2 * 684160}
 FOLDED_FLOP_EVAL = 2 * 256 * 256     # xyz_encoding_final: no tiles in the packed streams
 PEAK_F16_MFMA_TFLOPS = 2500.0     # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02_summary.json")
+def _latest_summary():
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_summary.json")))
+    return hits[-1] if hits else None
+
+
+PROFILE_SUMMARY = _latest_summary()     # the PMC passes (rocprofv3 --pmc, separate runs) cannot be made inside this process
 
 
 def parse_args(argv=None):
@@ -64,6 +70,15 @@ def parse_args(argv=None):
                     help="with --no-extras: this many forward-only steps after the timed ones (gives the PMC passes the "
                          "inference instantiation of the render kernel to count bytes on)")
     ap.add_argument("--dry", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and issue the gradient all-reduce at world size 1 too: exercises the "
+                         "RCCL path (init, in-place all-reduce on the gradient arena, capture in the step's graph) on one GPU")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="after the timed steps: keep stepping for this long with one HIP-event pair per step and report "
+                         "median / p90 (`sustained`); 0 = off")
+    ap.add_argument("--backward", default="f16", choices=["f16", "f16x3"],
+                    help="arithmetic of the MLP backward: f16 = single fp16 product (default), f16x3 = split operands, "
+                         "3 products, hi+lo stashes (fp32-class, the reference's precision class)")
     return ap.parse_args(argv)
 
 
@@ -80,7 +95,18 @@ def launch_ranks(args, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                    NFL_BENCH_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stderr=subprocess.PIPE,
+                                      text=True, bufsize=1))
+    import threading
+
+    def pump(r, stream):            # every line a rank writes to stderr is passed on with its rank in front
+        for line in stream:
+            sys.stderr.write(f"[rank {r}] {line}")
+        stream.close()
+
+    pumps = [threading.Thread(target=pump, args=(r, p.stderr), daemon=True) for r, p in enumerate(procs)]
+    for t in pumps:
+        t.start()
     rc, deadline = 0, None
     pending = set(range(args.gpus))
     while pending:
@@ -98,6 +124,8 @@ def launch_ranks(args, argv):
             for r in pending:
                 procs[r].kill()                          # exact PIDs this process started
         time.sleep(0.05)
+    for t in pumps:
+        t.join(timeout=5)
     return rc
 
 
@@ -210,16 +238,22 @@ def run_rank(args):
 
     import torch
     dist = None
-    if world > 1:
+    backend = None
+    if world > 1 or args.force_dist:
+        import datetime
+
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         backend = os.environ.get("NFL_BENCH_BACKEND", "nccl")      # "gloo": rehearsal of the N>1 path on one GPU
         if os.environ.get("NFL_BENCH_ONE_DEVICE"):
             local_rank = 0
+        rdv = datetime.timedelta(seconds=float(os.environ.get("NFL_BENCH_RDV_TIMEOUT", "180")))   # a rank that never arrives fails the run
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, timeout=rdv, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=rdv)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -227,7 +261,7 @@ def run_rank(args):
     from nerf_fl_amd import parallel, render_rays, synth
     from nerf_fl_amd import rendering as rnd
     from nerf_fl_amd.train import Adam, GraphedTrainStep, NerfWLoss
-    nerf_fl_amd.set_precision(args.precision)
+    nerf_fl_amd.set_precision(args.precision, backward=args.backward)
 
     R = args.rays
     cfg3 = args.workload == "cfg3"
@@ -241,28 +275,31 @@ def run_rank(args):
     params = [p for m in modules for p in m.parameters()]
     loss_fn = NerfWLoss()
     opt = Adam(params, lr=5e-4, eps=1e-8, capturable=args.graph)
+    arena = parallel.GradArena(params)       # flat gradient memory: written by the HIP backward, all-reduced in place
+    force = bool(args.force_dist)
 
     def render_step():
         with torch.no_grad():
             return render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False)
 
     def train_step():
-        opt.zero_grad(set_to_none=True)
         if args.unfused_loss:
-            res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False)
+            res = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False,
+                              grad_arena=arena)
             loss = sum(loss_fn(res, target).values())  # c_l + f_l (+ b_l + s_l), forward and backward one launch each
         else:       # NerfWLoss and its backward seeds in the render kernels' per-ray epilogue (losses.py:35-50)
             loss = render_rays(models, emb, rays, ts, N_SAMPLES, False, 1.0, 1.0, N_IMPORTANCE, 32768, white_back, False,
-                               loss_target=target)["_nerfw_loss"]
+                               loss_target=target, grad_arena=arena)["_nerfw_loss"]
         loss.backward()
         if dist is not None:
-            parallel.all_reduce_gradients(params)
+            arena.all_reduce(force=force)       # one in-place collective on the memory the backward wrote
         opt.step()
 
+    graphed = None
     if args.mode == "train" and args.graph:
         graphed = GraphedTrainStep(models, emb, params, opt, loss_fn if args.unfused_loss else None, rays, ts, target,
-                                   N_SAMPLES, N_IMPORTANCE,
-                                   white_back=white_back, all_reduce=dist is not None)
+                                   N_SAMPLES, N_IMPORTANCE, white_back=white_back, all_reduce=dist is not None,
+                                   arena=arena, force_all_reduce=force)
         step = graphed.replay
     else:
         step = train_step if args.mode == "train" else render_step
@@ -287,6 +324,14 @@ def run_rank(args):
         elapsed = float(t.item())
 
     n_ranks = dist.get_world_size() if dist is not None else 1
+    # sustained rate (>= 100 timed iterations, event-timed, median): outside the driver-specified steps, the
+    # same step for >= --sustained-seconds with one HIP event per step on the launch stream.  The step count is fixed
+    # from the (rank-maximised) timing above, so that every rank issues the same number of collectives.
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = max(100, int(args.sustained_seconds / max(elapsed / args.steps, 1e-6)) + 1)
+        sustained = event_timed(step, n_sus)
+        sync()
     sync_diff = None
     if dist is not None:
         # data parallelism keeps the replicas identical: same seeded weights, the same averaged gradients, the same Adam.
@@ -309,10 +354,16 @@ def run_rank(args):
         "unit": "ray-samples/s",
         "n_gpus": n_ranks,
         "ranks": n_ranks,
+        "backend": backend,
+        "all_reduce": (None if dist is None or args.mode != "train" else
+                       {"tensor": "one flat fp32 gradient arena, in place", "numel": int(arena.flat.numel()),
+                        "forced_at_world_1": force and n_ranks == 1,
+                        "captured_in_graph": bool(graphed is not None and graphed.captured_collective)}),
         "replica_param_max_diff": sync_diff,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "sustained": sustained,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -358,6 +409,23 @@ def run_rank(args):
     return 0
 
 
+def event_timed(fn, n):
+    """Run fn() n times with one HIP event after each call on the current stream; per-call durations (the time from
+    the previous event: kernels and any host gap between them) -> median / p90 / mean in ms."""
+    import torch
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    torch.cuda.synchronize()
+    evs[0].record()
+    for i in range(n):
+        fn()
+        evs[i + 1].record()
+        if i % 64 == 63:
+            evs[i - 31].synchronize()        # keep the host at most a few dozen steps ahead of the device
+    torch.cuda.synchronize()
+    d = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n))
+    return {"median_ms": d[n // 2], "p90_ms": d[min(n - 1, int(0.9 * n))], "mean_ms": sum(d) / n, "min_ms": d[0], "steps": n}
+
+
 def roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back):
     """Roofline of the dominant kernel: the fine-pass launch of nfl_render_kernel (R rays x 128 samples), timed
     alone with events on the launch stream, in the instantiation the timed mode runs (MODE 1 = training forward,
@@ -379,15 +447,8 @@ def roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back):
                                     white_back=white_back, stash=stash, **lat)
         for _ in range(5):
             run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 30
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
+        # >= 100 launches, one event pair each, on the stream the kernel is launched on (torch's current stream)
+        return event_timed(run, 200 if args.sustained_seconds > 0 else 30)
 
     base = _lib.lib().nfl_render_kernel_name(rnd._PREC[args.precision], 10).decode()      # "...<3, 1, 10, 0>"
     names = {False: base, True: base[:-2] + "1>"}
@@ -397,6 +458,13 @@ def roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back):
     summ = {}
     try:
         summ = json.load(open(PROFILE_SUMMARY))
+        # where the byte counts come from, and whether the library they were counted on is the one running now
+        import hashlib
+        prov = dict(summ.get("provenance") or {})
+        prov["file"] = os.path.relpath(PROFILE_SUMMARY, ROOT)
+        cur = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+        prov["matches_running_library"] = (prov.get("lib_sha16") == cur) if prov.get("lib_sha16") else None
+        summ["provenance"] = prov
     except Exception:
         pass
 
@@ -407,12 +475,14 @@ def roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back):
         return None
 
     def entry(stash):
-        ms = time_pass(stash)
+        t = time_pass(stash)
+        ms = t["mean_ms"]                 # average launch duration over the timed region (what rocprofv3 --stats averages too)
         ach = flops / (ms * 1e-3) / 1e12
         executed = FLOP_EVAL[fine_kind] - FOLDED_FLOP_EVAL
         return {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": traffic_of(names[stash]), "kernel": names[stash],
-                "launch_ms": ms, "executed_flops_per_eval": executed,
+                "launch_ms": ms, "launch_sustained": t, "traffic_source": summ.get("provenance"),
+                "executed_flops_per_eval": executed,
                 "frac_of_executed_flops": ach / PEAK_F16_MFMA_TFLOPS * executed / FLOP_EVAL[fine_kind],
                 "note": f"algorithmic FLOPs of the reference's field ({FLOP_EVAL[fine_kind]} per evaluation x {R} rays x {F} samples); "
                         f"the kernel executes {executed} of them (the linear xyz_encoding_final, 2 x 256 x 256, is folded into the "
@@ -424,6 +494,7 @@ def roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back):
         out["roofline_inference" if train else "roofline_training"] = entry(not train)
     st = summ.get("step_traffic")
     if st and args.mode == "train":
+        st = dict(st, source=summ.get("provenance"))
         out["step_traffic"] = st       # PMC HBM bytes of one whole train step vs its algorithmic bytes (profiles/)
     return out
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NFL_ABI_VERSION 7
+#define NFL_ABI_VERSION 8
 #define NFL_GMAX_SLOTS 1024
 
 enum {
@@ -138,7 +138,7 @@ typedef struct nfl_camera {
 
 typedef struct nfl_pass_args {
     /* geometry */
-    const float* d_rays;        /* (R,8): o(3) d(3) near far   (rendering.py:231-233); may be NULL when h_cam is set */
+    const float* d_rays;        /* (R,8): o(3) d(3) near far   (rendering.py:231-233); may be NULL when h_cam / d_cam is set */
     const nfl_camera* h_cam;    /* HOST pointer or NULL: generate the rays of this pass from the camera (copied at launch;
                                    inference only: not with d_act_stash)                                             */
     const float* d_view_dir;    /* (R,3) or NULL -> use rays_d (rendering.py:236-238)  */
@@ -206,6 +206,10 @@ typedef struct nfl_pass_args {
     /* used by nfl_field_forward only (leave NULL / 0 otherwise) */
     const float* d_embedded;
     int32_t n_points, embedded_stride;
+    /* the camera in DEVICE memory (same struct as h_cam; takes precedence over it): the launch then carries only the
+       pointer, so a pass captured in a HIP graph renders whatever camera the buffer holds at replay time (h_cam is copied
+       into the launch's arguments and would be frozen by the capture).  Must not change while the pass runs. */
+    const nfl_camera* d_cam;
 } nfl_pass_args;
 
 /* Evaluate the field on every sample of every ray and alpha-composite on the

@@ -7,9 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("NFL_LIB") or os.path.join(_HERE, "libnerf_fl_amd.so")
+# NFL_LIB selects a diagnostic / variant build of the library (make diag, make variant) -- honoured only in a
+# developer session (NERF_FL_AMD_DEV=1), so that a stray environment variable cannot swap the library under the product
+LIB_PATH = ((os.environ.get("NFL_LIB") if os.environ.get("NERF_FL_AMD_DEV") == "1" else None)
+            or os.path.join(_HERE, "libnerf_fl_amd.so"))
 
-NFL_ABI_VERSION = 7
+NFL_ABI_VERSION = 8
 NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
@@ -75,6 +78,7 @@ class PassArgs(C.Structure):
         ("loss_coef", C.c_float), ("lambda_u", C.c_float), ("loss_slot", C.c_int32), ("reserved2", C.c_int32),
         ("d_status", C.c_void_p),
         ("d_embedded", C.c_void_p), ("n_points", C.c_int32), ("embedded_stride", C.c_int32),
+        ("d_cam", C.c_void_p),
     ]
 
 

@@ -62,7 +62,8 @@ int nfl_render_pass(const void* h_plan, const void* d_plan, const void* d_packed
                     const nfl_pass_args* a, void* stream) {
     const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
     if (!hp || hp->magic != NFL_PLAN_MAGIC || !d_plan || !d_packed || !a) return NFL_EINVAL;
-    if (a->n_rays < 0 || a->n_samples < 1 || (!a->d_rays && !a->h_cam)) return NFL_EINVAL;
+    if (a->n_rays < 0 || a->n_samples < 1 || (!a->d_rays && !a->h_cam && !a->d_cam)) return NFL_EINVAL;
+    if (a->d_cam && a->d_act_stash) return NFL_EINVAL;
     if (a->h_cam && (a->d_act_stash || a->h_cam->width < 1 || a->h_cam->fx == 0.f || a->h_cam->fy == 0.f || a->h_cam->pix0 < 0))
         return NFL_EINVAL;
     if (!a->d_z && !a->d_lin) return NFL_EINVAL;
@@ -103,7 +104,7 @@ int nfl_field_forward(const void* h_plan, const void* d_plan, const void* d_pack
 
 int nfl_abi_version(void) { return NFL_ABI_VERSION; }
 
-const char* nfl_version(void) { return "nerf_fl_amd 0.1 (gfx950, HIP; abi 7)"; }
+const char* nfl_version(void) { return "nerf_fl_amd 0.1 (gfx950, HIP; abi 8)"; }
 
 const char* nfl_strerror(int code) {
     switch (code) {

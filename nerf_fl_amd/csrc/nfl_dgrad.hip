@@ -113,9 +113,6 @@ struct NflRingAux {
     }
     template <int P>
     NFL_DEV void piece() {
-#ifdef DG_ABL_NODMA
-        return;
-#endif
         if constexpr (P < MAXPW) {
             ops += 1;
             if (P == MAXPW - 1 && !i_mask) mk1 = ops;    // last piece of this chunk (unless its mask pieces follow)
@@ -211,9 +208,6 @@ struct DgEpi {
     template <int OP>
     NFL_DEV void pair() {
         constexpr int s = OP / 4, j = 2 * (OP % 4);
-#ifdef DG_ABL_NOEPI
-        if (OP != 0) return;
-#endif
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
@@ -229,11 +223,7 @@ struct DgEpi {
             // both stash stores of the tile are issued at its last pair-op, i.e. after every DMA piece of the
             // tile they ride in: the ring's counted vmcnt wait can then leave TWO tiles of stores outstanding
             // (the HBM write acknowledgement takes longer than one 16-MFMA row tile)
-#ifdef DG_ABL_NOSTORE
-            if (false) {
-#else
             if (OP == 7) {
-#endif
                 // streaming stores: the 2.6 GB of stash must not evict the weight stream from L2
                 __builtin_nontemporal_store(out[ks][cb][0], reinterpret_cast<h8*>(gst[cb] + slot * 1024));
                 __builtin_nontemporal_store(out[ks + 1][cb][0], reinterpret_cast<h8*>(gst[cb] + (slot + 1) * 1024));

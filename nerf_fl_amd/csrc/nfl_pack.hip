@@ -104,9 +104,6 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(const PackBatch B) {
         for (int j = 0; j < 8; ++j) {
             hi[j] = (_Float16)w[j];
             lo[j] = (_Float16)(w[j] - (float)hi[j]);
-#ifdef NFL_ABL_LO_MASK      // experiment: fewer significant bits in the residual operand (energy per MFMA -> clock?)
-            lo[j] = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, lo[j]) & NFL_ABL_LO_MASK));
-#endif
         }
         *reinterpret_cast<h8*>(dst) = hi;
         if (P.nsplit == 3) *reinterpret_cast<h8*>(dst + 1024) = lo;

@@ -29,6 +29,7 @@
 //     record.  Nothing per-sample except the API's own (R,N) outputs is written.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include <type_traits>
 
@@ -44,29 +45,10 @@ template <> struct nfl_elem<b8> { using type = __bf16; };
 __device__ __forceinline__ f16v nfl_mfma(h8 a, h8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f16v nfl_mfma(b8 a, b8 b, f16v c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 typedef float f4v __attribute__((ext_vector_type(4)));
-#ifdef NFL_ABL_MFMA16
-// TIMING ABLATION ONLY (results are wrong by construction): every 32x32x16 MFMA is issued as two 16x16x32 ones on
-// quarter Q and Q+1 of the same accumulator -- the same MFMA cycles, operand reads and register footprint as a
-// 16-row tiling of the kernel would have, under the kernel's real issue load
-template <int Q>
-__device__ __forceinline__ void nfl_mfma16x2(f16v& c, h8 a, h8 b) {
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int q = (Q + e) & 3;
-        f4v t = {c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]};
-        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, t, 0, 0, 0);
-        c[4 * q] = t[0]; c[4 * q + 1] = t[1]; c[4 * q + 2] = t[2]; c[4 * q + 3] = t[3];
-    }
-}
-#endif
 
 #define NFL_DEV __device__ __forceinline__
 // stash stores are streaming (nt): A/B on one box, training forward 1.69 ms with nt, 1.74 with plain stores (step 5.20 / 5.36 ms)
-#ifdef NFL_ABL_PLAIN_STASH
-#define NFL_STREAM_STORE(v, p) (*(p) = (v))
-#else
 #define NFL_STREAM_STORE(v, p) __builtin_nontemporal_store(v, p)
-#endif
 
 // compile-time loop: f(integral_constant<int, I>) for I in [I0, I1)
 template <int I0, int I1, class F>
@@ -281,11 +263,7 @@ struct NflRing {
     }
     template <int P>
     NFL_DEV void piece() {
-#ifdef NFL_ABL_NODMA
-        if constexpr (false) {
-#else
         if constexpr (P < MAXP) {
-#endif
             // uniform byte offset (SALU min), one VALU add for the lane: SGPR base + 32-bit VGPR offset
             unsigned byte = (unsigned)(wave + 4 * P) * 1024u;
             const unsigned last = (unsigned)i_nbytes - 1024u;
@@ -409,19 +387,6 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
         nfl_lds_wait<younger * NP, NP>(w[k % NW]);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-#ifdef NFL_ABL_MFMA16
-            if (NP == 2) {
-                nfl_mfma16x2<(2 * k) & 3>(acc[cb], __builtin_bit_cast(V8, w[k % NW][NP - 1]), getb(K, cb, 0));
-                if (cb == 0) {
-                    if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                nfl_mfma16x2<(2 * k + 2) & 3>(acc[cb], __builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, NP - 1));
-                if (cb == 0) ring.template piece<P0 + k>();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            nfl_mfma16x2<(2 * k) & 3>(acc[cb], __builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, 0));
-#else
             if (NP == 2) {
                 acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][NP - 1]), getb(K, cb, 0), acc[cb]);
                 if (cb == 0) {
@@ -433,7 +398,6 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, 0), acc[cb]);
-#endif
             if (NP == 1 && cb == 0) {
                 if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
                 ring.template piece<P0 + k>();
@@ -488,9 +452,6 @@ struct NflActEpi {
 
     template <int OP>
     NFL_DEV void pair() {                      // OP 0..7: elements 2*OP, 2*OP+1 of the 16 accumulators
-#ifdef NFL_ABL_NOEPI
-        if (OP != 0) return;
-#endif
         constexpr int s = OP / 4, j = 2 * (OP % 4);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
@@ -508,19 +469,13 @@ struct NflActEpi {
                 hi = nfl_pack2<_Float16>(x0, x1);
             }
             reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
-#ifndef NFL_ABL_NO_RANGE_TRACK
             {   // range tracking: after relu the halves are non-negative, so their bit patterns order like the values
                 const unsigned mag = RELU ? hi : (hi & 0x7fff7fffu);
                 asm("v_pk_max_u16 %0, %0, %1" : "+v"(ovf) : "v"(mag));
             }
-#endif
             if (STASH) {        // the fp16 hi operand IS the stashed activation
                 reinterpret_cast<unsigned(&)[4]>(tmp[cb])[j / 2] = hi;
-#ifdef NFL_ABL_NOSTASHST
-                if (OP % 4 == 3) asm volatile("" :: "v"(tmp[cb]));
-#else
                 if (OP % 4 == 3) NFL_STREAM_STORE(tmp[cb], reinterpret_cast<h8*>(stash[cb] + (slot + s) * 1024));
-#endif
                 if (RELU) {     // relu mask of the pair for the dgrad kernel: bit 2*OP / 16 + 2*OP (nfl_plan.h)
                     unsigned on;
                     asm("v_pk_min_u16 %0, %1, %2" : "=v"(on) : "v"(hi), "s"(0x00010001u));
@@ -529,13 +484,11 @@ struct NflActEpi {
                         // mask words are grouped by four tiles (mw0 is a multiple of 4 for every layer): lane l keeps
                         // words 4g..4g+3 in 16 contiguous bytes, record layout [group][lane][4]
                         mq[cb][MSLOT] = m32[cb];              // MSLOT = mword & 3, known at compile time
-#ifndef NFL_ABL_NOSTASHST
                         if (MSLOT == 3) {
                             typedef unsigned nfl_mq4 __attribute__((ext_vector_type(4)));
                             const nfl_mq4 v = {mq[cb][0], mq[cb][1], mq[cb][2], mq[cb][3]};
                             NFL_STREAM_STORE(v, reinterpret_cast<nfl_mq4*>(mstash[cb] + (mword >> 2) * 1024));
                         }
-#endif
                     }
                 }
             }
@@ -654,11 +607,7 @@ struct NflRenderCfg {
     static constexpr int KSB = 1024 * NP;
     static constexpr int MAXKS = 16 + (NKP > 5 ? NKP : 5);
     static constexpr int SLOT = MAXKS * KSB;
-#ifdef NFL_ABL_MAXP
-    static constexpr int MAXP = NFL_ABL_MAXP;        // ablation only: chunks longer than 4 KiB * MAXP are truncated
-#else
     static constexpr int MAXP = (SLOT + 4095) / 4096;
-#endif
     static constexpr int NSLOT = 4 * NCB;
     static constexpr int LDS_RING = 3 * SLOT;
     static constexpr int LDS_BIAS = NFL_MAX_RT * 32 * 4;
@@ -686,11 +635,7 @@ extern "C" int nfl_debug_stamps(unsigned long long* host, int n_entries) {
 #define NFL_STAMP(i) do {} while (0)
 #endif
 
-#ifdef NFL_ABL_NO_LOSS
-#define NFL_LOSS_ON(a) false
-#else
 #define NFL_LOSS_ON(a) ((a).d_loss_target != nullptr)
-#endif
 // The kernel's argument block, re-read from the kernarg segment.  Values loaded through the returned pointer cannot be
 // hoisted above the call (the empty asm makes the pointer opaque), so arguments that are only needed in the cold parts
 // of a tile (ray set-up, compositing, outputs, loss) are s_load'ed there instead of being kept in SGPRs -- or rather in
@@ -701,6 +646,13 @@ NFL_DEV NflKArgs nfl_kargs() {
     NflKArgs p = (NflKArgs)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
+}
+
+// the camera of a ray-generating pass: in the kernarg segment (copied from nfl_pass_args::h_cam at launch) or, when the
+// caller keeps it in device memory (d_cam: graph replays), behind that pointer -- read with scalar loads either way
+typedef const __attribute__((address_space(4))) nfl_camera* NflKCam;
+NFL_DEV NflKCam nfl_kcam(NflKArgs K) {
+    return K->a.d_cam ? (NflKCam)(unsigned long long)K->a.d_cam : &K->cam;
 }
 
 #define NFL_MODE_RENDER 0
@@ -804,11 +756,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 continue;
             }
             f4v r0, r1;
-#ifndef NFL_ABL_NO_CAM
             if (K->gen_rays) {
-                nfl_cam_ray(K->cam, K->cam.pix0 + ray, r0, r1);
+                const NflKCam cam = nfl_kcam(K);
+                nfl_cam_ray(*cam, cam->pix0 + ray, r0, r1);
             } else
-#endif
             {
                 const float* rp = K->a.d_rays + (size_t)ray * 8;
                 r0 = *reinterpret_cast<const f4v*>(rp);
@@ -901,13 +852,10 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         continue;
                     }
                     float raw[3], th[3], tl[3];
-#ifndef NFL_ABL_NO_CAM
                     if (K->gen_rays && !K->a.d_view_dir) {
-#else
-                    if (false) {
-#endif
                         f4v g0, g1;
-                        nfl_cam_ray(K->cam, K->cam.pix0 + s_ray[cb], g0, g1);
+                        const NflKCam cam = nfl_kcam(K);
+                        nfl_cam_ray(*cam, cam->pix0 + s_ray[cb], g0, g1);
                         raw[0] = g0[3];
                         raw[1] = g1[0];
                         raw[2] = g1[1];
@@ -1225,11 +1173,12 @@ static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void
     A.n_points = 0;
     A.emb_stride = 0;
     A.gen_rays = 0;
-    if (args->h_cam != nullptr && MODE != NFL_MODE_EMBED) {
+    memset(&A.cam, 0, sizeof(A.cam));
+    if ((args->h_cam != nullptr || args->d_cam != nullptr) && MODE != NFL_MODE_EMBED) {
         A.gen_rays = 1;
-        A.cam = *args->h_cam;
-        A.a.h_cam = nullptr;              // a host pointer has no business on the device
+        if (args->h_cam != nullptr && args->d_cam == nullptr) A.cam = *args->h_cam;
     }
+    A.a.h_cam = nullptr;                  // a host pointer has no business on the device
     if (MODE == NFL_MODE_EMBED) {      // n_rays = segments of 32 points; d_t_emb != NULL only flags "transient head on"
         A.n_points = args->n_points;
         A.emb_stride = args->embedded_stride;

@@ -19,71 +19,128 @@ __all__ = ["batched_inference", "GraphedChunk", "frame_rays", "to_uint8", "dolly
 
 
 class GraphedChunk:
-    """One fixed-shape render_rays(test_time=True) call captured in a HIP graph."""
+    """One fixed-shape render_rays(test_time=True) call captured in a HIP graph.
 
-    def __init__(self, models, embeddings, chunk, device, N_samples, use_disp, N_importance, white_back, **kwargs):
-        self.chunk = chunk
+    Everything that varies between replays lives in static device buffers the captured kernels read: the ray matrix (or,
+    for `CameraRays` input, the camera struct: the render kernel's prologue generates the rays from it -- C ABI
+    nfl_pass_args::d_cam), `ts`, and the per-ray kwargs `a_embedded` / `t_embedded` / `view_dir`.  The packed weight
+    streams are NOT part of the graph: `__call__` compares the fields' parameter keys (data pointers + version counters)
+    with the ones the streams were packed from and re-packs eagerly before the replay when they moved (an optimizer
+    step, load_state_dict), so a cached graph never renders stale weights."""
+
+    PER_RAY = ("a_embedded", "t_embedded", "view_dir")
+
+    def __init__(self, models, embeddings, chunk, device, N_samples, use_disp, N_importance, white_back, camera=False,
+                 **kwargs):
+        import weakref
+
+        from . import rendering as rnd
+        self.chunk, self.device = chunk, torch.device(device)
+        self.camera = bool(camera)
+        self.model_refs = {k: weakref.ref(m) for k, m in models.items()}
         self.rays = torch.zeros(chunk, 8, device=device)
         self.rays[:, 3:6] = torch.tensor([0.0, 0.0, -1.0], device=device)
         self.rays[:, 6], self.rays[:, 7] = 2.0, 6.0
         self.ts = torch.zeros(chunk, dtype=torch.long, device=device)
         self.kw_static = {}
-        for k in ("a_embedded", "t_embedded"):       # per-frame latent overrides (test_phototourism.ipynb cell 11)
+        for k in self.PER_RAY:       # per-frame latent overrides (test_phototourism.ipynb cell 11), per-ray view directions
             if kwargs.get(k) is not None:
-                self.kw_static[k] = kwargs[k].expand(chunk, -1).contiguous().clone()
-        other = {k: v for k, v in kwargs.items() if k not in self.kw_static}
+                v = kwargs[k].to(device=device, dtype=torch.float32)
+                self.kw_static[k] = v[:1].expand(chunk, -1).contiguous().clone()
+        other = {k: v for k, v in kwargs.items() if k not in self.PER_RAY}
+        self.cam_rays = None
+        if self.camera:             # a 1 x 1 frame as a placeholder; __call__ overwrites the device-side struct
+            self.cam_rays = CameraRays(torch.eye(4)[:3], torch.eye(3), 1, 1, 2.0, 6.0, device, count=0)
+            self.cam_rays.count, self.cam_rays.shape = chunk, (chunk, 8)
+            self.cam_rays.to_device()
 
         def run():
-            return render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, 0, 0, N_importance,
-                               chunk, white_back, True, **self.kw_static, **other)
+            return render_rays(models, embeddings, self.cam_rays if self.camera else self.rays, self.ts, N_samples, use_disp,
+                               0, 0, N_importance, chunk, white_back, True, **self.kw_static, **other)
 
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side), torch.no_grad():      # warm-up: packs weights, sets kernel attributes
             run()
         torch.cuda.current_stream(device).wait_stream(side)
+        n_xyz, n_dir = rnd._n_freqs(embeddings["xyz"]), rnd._n_freqs(embeddings["dir"])
+        self.fields = [rnd._field(m, n_xyz, n_dir, self.device, pack=False) for m in models.values()]
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.out = run()
 
-    def __call__(self, rays, ts, **latents):
+    def alive_for(self, models):
+        """The captured launches read THESE models' packed streams: a cache hit must be for the same module objects."""
+        return set(models) == set(self.model_refs) and all(self.model_refs[k]() is m for k, m in models.items())
+
+    def __call__(self, rays, ts, **per_ray):
+        from . import rendering as rnd
         n = rays.shape[0]
-        if isinstance(rays, CameraRays):      # a captured launch freezes by-value arguments (the camera): materialise
-            rays = frame_rays_of(rays)        # the rows into the static buffer with nfl_gen_rays instead
-        self.rays[:n].copy_(rays)
+        if n > self.chunk:
+            raise ValueError(f"GraphedChunk captured for {self.chunk} rays, got {n}")
+        if isinstance(rays, CameraRays):
+            if self.camera:          # 88 bytes to the device-side camera struct the captured prologue reads
+                self.cam_rays.load(rays)
+            else:                    # captured on a ray matrix: materialise the rows with nfl_gen_rays
+                rays = frame_rays_of(rays)
+        elif self.camera:
+            raise ValueError("this GraphedChunk was captured for CameraRays input")
+        if not isinstance(rays, CameraRays):
+            self.rays[:n].copy_(rays)
+            if n < self.chunk:                                   # ragged tail: repeat the last ray
+                self.rays[n:].copy_(rays[-1:].expand(self.chunk - n, -1))
         if ts is not None:
             self.ts[:n].copy_(ts)
-        if n < self.chunk:                                   # ragged tail: repeat the last ray
-            self.rays[n:].copy_(rays[-1:].expand(self.chunk - n, -1))
-            if ts is not None:
+            if n < self.chunk:
                 self.ts[n:].copy_(ts[-1:].expand(self.chunk - n))
+        if set(per_ray) - set(self.kw_static):
+            raise ValueError(f"per-ray kwargs {sorted(set(per_ray) - set(self.kw_static))} were not part of the capture")
         for k, buf in self.kw_static.items():
-            if k in latents:
-                v = latents[k]
-                if v.shape[0] == 1:
-                    buf.copy_(v.expand(self.chunk, -1))
-                else:                                        # per-ray values of a (possibly ragged) chunk
-                    buf[:n].copy_(v)
-                    if n < self.chunk:
-                        buf[n:].copy_(v[-1:].expand(self.chunk - n, -1))
+            if k not in per_ray:
+                raise ValueError(f"this GraphedChunk was captured with `{k}`: pass it on every call")
+            v = per_ray[k]
+            if v.shape[0] == 1:
+                buf.copy_(v.expand(self.chunk, -1))
+            else:                                            # per-ray values of a (possibly ragged) chunk
+                buf[:n].copy_(v)
+                if n < self.chunk:
+                    buf[n:].copy_(v[-1:].expand(self.chunk - n, -1))
+        # weights moved since the streams were packed (optimizer step, load_state_dict)?  re-pack eagerly: the captured
+        # kernels read the same buffers
+        rnd._pack_streams(self.fields, bwd=False, rays_grad=False)
         self.graph.replay()
         return {k: v[:n] for k, v in self.out.items()}
+
+
+_GRAPH_CACHE = {}      # default cache of batched_inference(use_graph=True): one capture per distinct launch sequence
+
+
+def _graph_key(models, embeddings, rays, chunk, N_samples, N_importance, use_disp, white_back, kwargs):
+    """Everything that changes the captured launch sequence or the buffers it reads."""
+    from . import rendering as rnd
+    return (chunk, N_samples, N_importance, bool(use_disp), bool(white_back), str(rays.device), isinstance(rays, CameraRays),
+            tuple(sorted((k, id(m)) for k, m in models.items())), tuple(sorted((k, id(e)) for k, e in embeddings.items())),
+            tuple(sorted(k for k in kwargs if kwargs[k] is not None and k in GraphedChunk.PER_RAY)),
+            tuple(sorted((k, repr(v)) for k, v in kwargs.items() if k not in GraphedChunk.PER_RAY)),
+            rnd.get_precision())
 
 
 @torch.no_grad()
 def batched_inference(models, embeddings, rays, ts, N_samples, N_importance, use_disp=False, chunk=1024 * 128,
                       white_back=False, use_graph=False, _graph_cache=None, **kwargs):
     """Same arguments as the reference's eval.batched_inference (eval.py:80-88) plus `use_graph`.
-    Returns a dict of GPU tensors covering all `rays`."""
+    Returns a dict of GPU tensors covering all `rays`.  With `use_graph` the chunk is captured once per distinct call
+    signature (models, kwargs present, `output_transient`, shapes, precision) and kept in `_graph_cache` (default: a
+    module-level cache), so repeated calls replay instead of re-capturing."""
     B = rays.shape[0]
     results = {}
     runner = None
     if use_graph:
-        key = (chunk, N_samples, N_importance, bool(use_disp), bool(white_back), str(rays.device))
-        cache = _graph_cache if _graph_cache is not None else {}
-        if key not in cache:
+        key = _graph_key(models, embeddings, rays, chunk, N_samples, N_importance, use_disp, white_back, kwargs)
+        cache = _graph_cache if _graph_cache is not None else _GRAPH_CACHE
+        if key not in cache or not cache[key].alive_for(models):
             cache[key] = GraphedChunk(models, embeddings, chunk, rays.device, N_samples, use_disp, N_importance,
-                                      white_back, **kwargs)
+                                      white_back, camera=isinstance(rays, CameraRays), **kwargs)
         runner = cache[key]
     for i in range(0, B, chunk):
         r = rays.slice(i, i + chunk) if isinstance(rays, CameraRays) else rays[i:i + chunk]
@@ -92,7 +149,7 @@ def batched_inference(models, embeddings, rays, ts, N_samples, N_importance, use
         # per-ray kwargs follow their chunk: a (B, C) tensor is sliced, a (1, C) one (one latent code for the whole
         # frame, test_phototourism.ipynb cell 11) is broadcast
         per_ray = {}
-        for k in ("a_embedded", "t_embedded", "view_dir"):
+        for k in GraphedChunk.PER_RAY:
             v = kwargs.get(k)
             if v is not None:
                 per_ray[k] = v[i:i + chunk] if v.shape[0] == B and B != 1 else v.expand(n, -1)
@@ -183,7 +240,7 @@ def render_video(models, embeddings, poses, K, H, W, near, far, N_samples, N_imp
     parallel.shard_bounds(n_frames, r, world) and returns (first frame index, uint8 (n_local, H, W, 3)).  (The
     reference renders every frame on one GPU, eval.py:186-194.)"""
     lo, hi = parallel.shard_bounds(len(poses), rank, world)
-    cache = kwargs.pop("_graph_cache", {})
+    cache = kwargs.pop("_graph_cache", None)        # None: the module-level cache of batched_inference
     frames = [render_frame(models, embeddings, poses[i], K, H, W, near, far, N_samples, N_importance, _graph_cache=cache,
                            **kwargs)[0] for i in range(lo, hi)]
     dev = kwargs.get("device", "cuda:0")

@@ -33,22 +33,37 @@ import torch
 
 from . import _lib
 
-__all__ = ["render_rays", "set_precision", "get_precision", "check_status", "CameraRays"]
+__all__ = ["render_rays", "set_precision", "get_precision", "get_backward_precision", "check_status", "CameraRays"]
 
 _PREC = {"f16x3": _lib.NFL_PREC_F16X3, "f16": _lib.NFL_PREC_F16}
 _precision = os.environ.get("NERF_FL_AMD_PREC", "f16x3")
+_backward = os.environ.get("NERF_FL_AMD_BWD", "f16")
 
 
-def set_precision(name):
-    """'f16x3' (default; fp16 MFMA with split operands, fp32-class accuracy) or 'f16' (fast)."""
-    global _precision
-    if name not in _PREC:
-        raise ValueError(f"precision must be one of {sorted(_PREC)}")
-    _precision = name
+def set_precision(name=None, backward=None):
+    """Forward arithmetic `name`: 'f16x3' (default; fp16 MFMA with split operands, 3 products, fp32-class accuracy) or
+    'f16' (single product; fast, inference only).
+    `backward`: arithmetic of the MLP part of the hand-written backward (dgrad + wgrad): 'f16' (default: single fp16
+    products on fp16 stashes under a loss scale, gradients within a few 1e-3 of fp32 autograd) or 'f16x3' (split
+    operands hi+lo, 3 products, hi+lo activation / gradient stashes: the reference's fp32 precision class, at about twice
+    the backward's HBM traffic and three times its matrix work)."""
+    global _precision, _backward
+    if name is not None:
+        if name not in _PREC:
+            raise ValueError(f"precision must be one of {sorted(_PREC)}")
+        _precision = name
+    if backward is not None:
+        if backward not in ("f16", "f16x3"):
+            raise ValueError("backward must be 'f16' or 'f16x3'")
+        _backward = backward
 
 
 def get_precision():
     return _precision
+
+
+def get_backward_precision():
+    return _backward
 
 
 def _ptr(t):
@@ -87,7 +102,28 @@ class CameraRays:
         out.start, out.count, out.shape = self.start + lo, hi - lo, (hi - lo, 8)
         out.cam = _lib.Camera.from_buffer_copy(self.cam)
         out.cam.pix0 = self.start + lo
+        out.d_cam = None
         return out
+
+    d_cam = None       # device copy of the camera struct (to_device): the pass then reads the camera through a pointer
+
+    def to_device(self):
+        """Keep the camera in device memory (C ABI nfl_pass_args::d_cam): a render pass captured in a HIP graph then
+        renders whatever `load()` last put there, instead of the camera frozen into the captured launch."""
+        if self.d_cam is None:
+            self.d_cam = torch.zeros(C.sizeof(_lib.Camera), dtype=torch.uint8, device=self.device)
+        self.d_cam.copy_(torch.frombuffer(bytearray(bytes(self.cam)), dtype=torch.uint8))
+        return self
+
+    def load(self, other):
+        """Take over `other`'s camera and pixel range, keeping this object's device buffer.  (A captured launch renders
+        its fixed number of rays whatever the range holds: rows past `other.count` are the pixels that follow in row-major
+        order -- beyond the last row of the frame they are simply rays below it; nothing is indexed by pixel -- and the
+        caller drops them.)"""
+        self.cam = _lib.Camera.from_buffer_copy(other.cam)
+        self.H, self.W, self.start = other.H, other.W, other.start
+        self.to_device()
+        return self
 
 
 _status_words = {}
@@ -164,6 +200,7 @@ class _PackedField:
         self.fold = None          # folded copies of dir_encoding.0 / transient_encoding.0 (weight, bias) for the packer
         self.bplans = {}          # rays_grad -> dict(h, d, packed, nbytes, key)
         self.wplans = {}          # use_transient -> (host blob, device copy) of the wgrad job list
+        self.wg_scratch = None    # composition scratch of nfl_mlp_wgrad when the gradients go to a caller-owned GradArena
 
     def _named(self):
         """name -> nn.Parameter, as dict(model.named_parameters()) but without walking the module tree on every call (73 us
@@ -409,6 +446,7 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     a = _lib.PassArgs()
     if isinstance(rays, CameraRays):
         a.d_rays, a.h_cam = C.c_void_p(0), C.pointer(rays.cam)
+        a.d_cam = _ptr(rays.d_cam)
     else:
         a.d_rays = _ptr(rays)
     a.d_view_dir = _ptr(view_dir)
@@ -551,10 +589,19 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(field.desc), R, N), dtype=torch.uint8, device=dev)
     g_a = g_t = None
     tables = cfg["latent_tables"]
+    arena = cfg["arena"]
+
+    def latent_grad(table, n_vocab, width):
+        # with a GradArena the table gradient is accumulated in place (the view is zeroed first, as a fresh tensor would be)
+        v = arena.view(table) if (arena is not None and tables and table is not None) else None
+        if v is not None:
+            return v.zero_()
+        return torch.zeros(n_vocab if tables else R, width, dtype=torch.float32, device=dev)
+
     if want_latents and field.desc.encode_appearance:
-        g_a = torch.zeros(cfg["n_vocab_a"] if tables else R, field.desc.n_a, dtype=torch.float32, device=dev)
+        g_a = latent_grad(cfg.get("table_a"), cfg.get("n_vocab_a"), field.desc.n_a)
     if want_latents and use_t:
-        g_t = torch.zeros(cfg["n_vocab_t"] if tables else R, field.desc.n_tau, dtype=torch.float32, device=dev)
+        g_t = latent_grad(cfg.get("table_t"), cfg.get("n_vocab_t"), field.desc.n_tau)
     da = _lib.DgradArgs()
     da.d_head_grads, da.d_act_stash, da.d_grad_stash = _ptr(head), _ptr(st["act"]), _ptr(grad_stash)
     da.n_rays, da.n_samples, da.use_transient = R, N, int(use_t)
@@ -568,22 +615,32 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     _lib.check(L.nfl_mlp_dgrad(bp["h"], _ptr(bp["d"]), _ptr(bp["packed"]), C.byref(da), _stream()), "nfl_mlp_dgrad")
 
     plist = field.param_list()
-    n_par = sum(w.numel() + b.numel() for _, w, b in plist)
-    n_scr = L.nfl_wgrad_scratch_bytes() // 4       # composition scratch (G: include/nerf_fl_amd.h, nfl_mlp_wgrad), behind the gradients
-    arena = torch.empty(n_scr + n_par, dtype=torch.float32, device=dev)   # zeroed by the call; scratch first (16-byte aligned)
+    n_scr = L.nfl_wgrad_scratch_bytes() // 4       # composition scratch (G: include/nerf_fl_amd.h, nfl_mlp_wgrad)
     fg = _lib.FieldGrads()
-    views, off = [], n_scr
-    for i, w, b in plist:
-        gw = arena[off:off + w.numel()].view_as(w)
-        off += w.numel()
-        gb = arena[off:off + b.numel()].view_as(b)
-        off += b.numel()
-        fg.weight[i], fg.bias[i] = gw.data_ptr(), gb.data_ptr()
-        views += [gw, gb]
+    views = []
+    if arena is not None and all(arena.view(p) is not None for _, w, b in plist for p in (w, b)):
+        # the caller's GradArena owns the gradient memory (p.grad are views of it): written in place, nothing returned
+        if field.wg_scratch is None:
+            field.wg_scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        scratch = field.wg_scratch
+        for i, w, b in plist:
+            fg.weight[i], fg.bias[i] = arena.view(w).data_ptr(), arena.view(b).data_ptr()
+            views += [None, None]
+    else:
+        n_par = sum(w.numel() + b.numel() for _, w, b in plist)
+        scratch = torch.empty(n_scr + n_par, dtype=torch.float32, device=dev)   # zeroed by the call; scratch first (16-byte aligned)
+        off = n_scr
+        for i, w, b in plist:
+            gw = scratch[off:off + w.numel()].view_as(w)
+            off += w.numel()
+            gb = scratch[off:off + b.numel()].view_as(b)
+            off += b.numel()
+            fg.weight[i], fg.bias[i] = gw.data_ptr(), gb.data_ptr()
+            views += [gw, gb]
     h_wp, d_wp = field.wgrad_plan(use_t)
     fp, _keep = field._field_params()          # the fp32 weights the forward ran with (read by the composition)
     _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), _ptr(gmax), R, N, C.byref(fp),
-                               C.c_void_p(arena.data_ptr()), C.byref(fg), _stream()),
+                               C.c_void_p(scratch.data_ptr()), C.byref(fg), _stream()),
                "nfl_mlp_wgrad")
     return views, g_a, g_t
 
@@ -642,6 +699,12 @@ class _RenderRaysFn(torch.autograd.Function):
                 out += vf
         ga = g_a if (ctx.a_emb is not None and ctx.needs_input_grad[2]) else None
         gt = g_t if (ctx.t_emb is not None and ctx.needs_input_grad[3]) else None
+        arena = cfg["arena"]
+        if arena is not None:       # gradients written in place into the arena's views: make sure p.grad IS that view
+            arena.attach()
+            if cfg["latent_tables"]:
+                ga = None if (ga is not None and arena.view(cfg.get("table_a")) is not None) else ga
+                gt = None if (gt is not None and arena.view(cfg.get("table_t")) is not None) else gt
         return (None, g_rays if ctx.needs_input_grad[1] else None, ga, gt, *out)
 
 
@@ -668,7 +731,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                    white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
                    view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
                    use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None, loss=None,
-                   latent_tables=False, ts=None)
+                   latent_tables=False, ts=None, arena=kwargs.get("grad_arena"))
         if kwargs.get("loss_target") is not None:
             # build-defined: NerfWLoss (losses.py:35-50) fused into the per-ray epilogue of the training passes.  The result
             # gains `_nerfw_loss` (scalar, the only output that carries gradient then) and `_nerfw_terms` (4,)
@@ -726,8 +789,8 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                 cfg["ts"] = ts.detach().to(device=dev, dtype=torch.int64).contiguous()
                 if cfg["ts"].shape != (R,):
                     raise ValueError(f"ts must be ({R},)")
-                a_emb = embeddings["a"].weight if need_a else None
-                t_emb = embeddings["t"].weight if need_t else None
+                a_emb = cfg["table_a"] = embeddings["a"].weight if need_a else None
+                t_emb = cfg["table_t"] = embeddings["t"].weight if need_t else None
             else:
                 if need_a:
                     a_emb = kwargs["a_embedded"] if "a_embedded" in kwargs else embeddings["a"](ts)

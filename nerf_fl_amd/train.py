@@ -34,21 +34,10 @@ class NerfWLoss(nn.Module):
         self.coef, self.lambda_u = coef, lambda_u
 
     def forward(self, inputs, targets):
-        if targets.is_cuda:
-            return self._fused(inputs, targets)
-        ret = {"c_l": 0.5 * ((inputs["rgb_coarse"] - targets) ** 2).mean()}
-        if "rgb_fine" in inputs:
-            if "beta" not in inputs:
-                ret["f_l"] = 0.5 * ((inputs["rgb_fine"] - targets) ** 2).mean()
-            else:
-                beta = inputs["beta"]
-                ret["f_l"] = ((inputs["rgb_fine"] - targets) ** 2 / (2 * beta.unsqueeze(1) ** 2)).mean()
-                ret["b_l"] = 3 + torch.log(beta).mean()
-                ret["s_l"] = self.lambda_u * inputs["transient_sigmas"].mean()
-        return {k: self.coef * v for k, v in ret.items()}
-
-    def _fused(self, inputs, targets):
-        """Same terms through the C ABI (nfl_loss_forward / nfl_loss_backward): two launches instead of ~16."""
+        """The terms through the C ABI (nfl_loss_forward / nfl_loss_backward): two launches instead of ~16.  Device tensors
+        only, like everything in this package (the CPU restatement of the loss is oracle/nerfw_oracle.py: nerfw_loss)."""
+        if not targets.is_cuda:
+            raise RuntimeError("nerf_fl_amd.train.NerfWLoss: device tensors only (this build has no CPU path)")
         rgb_f, beta = inputs.get("rgb_fine"), inputs.get("beta")
         tsig = inputs.get("transient_sigmas") if beta is not None else None
         c_l, f_l, b_l, s_l = _FusedNerfWLoss.apply(inputs["rgb_coarse"], rgb_f, beta, tsig, targets, float(self.coef),
@@ -119,10 +108,14 @@ class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, capturable=False):
         """capturable=True: learning rate, betas, eps and the step count are kept in device memory and read by the
         kernel (C ABI `nfl_adam_step_dev`), so `step()` can be captured in a HIP graph and replayed while a scheduler
-        changes the rate (GraphedTrainStep); `sync_hyper()` uploads the current param_groups' values."""
+        changes the rate (GraphedTrainStep); `sync_hyper()` uploads the current param_groups' values.
+        The device-side step count is ONE counter per (param group, device), seeded from the largest host-side step of
+        the group: all tensors of a group share their bias corrections (torch.optim.Adam counts per parameter; the two
+        agree whenever every parameter of a group receives a gradient at every step, which is how this package trains)."""
+        self._dev = {}            # (group index, device) -> dict(hyper=float[4] tensor, step=int32 tensor, host=tuple)
+        self._captured = set()    # id(p) of the parameters a captured step() updates
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
         self.capturable = bool(capturable)
-        self._dev = {}            # (group index, device) -> dict(hyper=float[4] tensor, step=int32 tensor, host=tuple)
 
     def _dev_state(self, gi, group, dev):
         k = (gi, str(dev))
@@ -131,6 +124,18 @@ class Adam(torch.optim.Optimizer):
             self._dev[k] = dict(hyper=torch.zeros(4, dtype=torch.float32, device=dev),
                                 step=torch.full((1,), max(steps) if steps else 0, dtype=torch.int32, device=dev), host=None)
         return self._dev[k]
+
+    def load_state_dict(self, state_dict):
+        """torch's loader, then the device-side step counters of a capturable optimizer are dropped so that the next
+        step() re-seeds them from the loaded state (bias corrections follow the checkpoint, not the steps this object took
+        before)."""
+        super().load_state_dict(state_dict)
+        self._dev = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        if getattr(self, "_dev", None):
+            self._dev = {}
 
     def sync_hyper(self):
         """Upload lr / betas / eps of every param group to the device copies the captured launches read (host -> device
@@ -143,10 +148,11 @@ class Adam(torch.optim.Optimizer):
                 st["host"] = host
 
     def note_replay(self):
-        """A captured step() was replayed: advance the host-side step counts (state_dict compatibility)."""
+        """A captured step() was replayed: advance the host-side step counts (state_dict compatibility) of the parameters
+        the captured launch updates (those that had a gradient when it was captured)."""
         for group in self.param_groups:
             for p in group["params"]:
-                if self.state.get(p):
+                if self.state.get(p) and (not self._captured or id(p) in self._captured):
                     self.state[p]["step"] = int(self.state[p]["step"]) + 1
 
     @torch.no_grad()
@@ -177,6 +183,8 @@ class Adam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 if not capturing:                # a captured launch runs at replay time: note_replay() counts it
                     st["step"] = int(st["step"]) + 1
+                else:
+                    self._captured.add(id(p))
                 if not p.is_contiguous():
                     raise RuntimeError("nerf_fl_amd.train.Adam: parameters must be contiguous")
                 # capturable: one device-side counter per (group, device), so all of a group's tensors step together
@@ -224,26 +232,43 @@ class GraphedTrainStep:
     With `all_reduce=True` (ranks > 1) the step is two graphs with the flat gradient all-reduce between them."""
 
     def __init__(self, models, embeddings, params, opt, loss_fn, rays, ts, target, N_samples, N_importance,
-                 use_disp=False, perturb=1.0, noise_std=1.0, white_back=True, all_reduce=False, warmup=2):
+                 use_disp=False, perturb=1.0, noise_std=1.0, white_back=True, all_reduce=False, warmup=2,
+                 loss_coef=1.0, lambda_u=0.01, arena=None, capture_all_reduce=None, force_all_reduce=False):
+        """loss_coef / lambda_u: NerfWLoss's constants for the fused loss (loss_fn=None); with a loss_fn they are its own.
+        arena: the GradArena that holds the parameters' gradients (created here when None): the backward writes into it
+        and the all-reduce runs on it in place.
+        capture_all_reduce: record the collective INSIDE the one graph (RCCL supports stream capture); None = yes for
+        the nccl backend, no otherwise (gloo cannot be captured: the step is then two graphs around an eager collective).
+        force_all_reduce: issue the collective at world size 1 too (exercises RCCL on a single GPU)."""
         if not getattr(opt, "capturable", False):
             raise ValueError("GraphedTrainStep needs nerf_fl_amd.train.Adam(capturable=True)")
+        import torch.distributed as dist
         self.params, self.opt, self.all_reduce = list(params), opt, bool(all_reduce)
         self.rays, self.ts, self.target = rays.detach().clone(), ts.detach().clone(), target.detach().clone()
+        self.arena = arena if arena is not None else parallel.GradArena(self.params)
+        self.force = bool(force_all_reduce)
+        if capture_all_reduce is None:
+            capture_all_reduce = self.all_reduce and dist.is_initialized() and dist.get_backend() == "nccl"
+        self.captured_collective = bool(capture_all_reduce) and self.all_reduce
         dev = self.rays.device
 
         def fwd_bwd():
-            opt.zero_grad(set_to_none=True)
+            # (parameters the backward never reaches keep the zeros the arena was created with)
             if loss_fn is None:      # NerfWLoss fused into the render kernels' per-ray epilogue (render_rays: loss_target)
                 res = render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, perturb, noise_std,
-                                  N_importance, 32768, white_back, False, loss_target=self.target)
+                                  N_importance, 32768, white_back, False, loss_target=self.target,
+                                  loss_coef=loss_coef, lambda_u=lambda_u, grad_arena=self.arena)
                 total = res["_nerfw_loss"]
             else:
                 res = render_rays(models, embeddings, self.rays, self.ts, N_samples, use_disp, perturb, noise_std,
-                                  N_importance, 32768, white_back, False)
+                                  N_importance, 32768, white_back, False, grad_arena=self.arena)
                 total = sum(loss_fn(res, self.target).values())
             total.backward()
             key = "rgb_fine" if "rgb_fine" in res else "rgb_coarse"
             return total.detach(), psnr(res[key].detach(), self.target)
+
+        def reduce():
+            self.arena.all_reduce(force=self.force)
 
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -251,17 +276,23 @@ class GraphedTrainStep:
             for _ in range(max(1, warmup)):
                 fwd_bwd()
                 if self.all_reduce:
-                    parallel.all_reduce_gradients(self.params)
+                    reduce()
                 opt.step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        missing = [i for i, p in enumerate(self.params) if p.requires_grad and p.grad is None]
+        if missing:      # a captured opt.step() would skip them for ever
+            raise RuntimeError(f"GraphedTrainStep: {len(missing)} trainable parameters have no gradient after the warm-up "
+                               f"steps (first: index {missing[0]}); pass only parameters the step reaches")
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
         with torch.cuda.graph(self.graph):
             self.out = fwd_bwd()
-            if not self.all_reduce:
+            if self.all_reduce and self.captured_collective:
+                reduce()
+            if not self.all_reduce or self.captured_collective:
                 opt.step()
-        if self.all_reduce:
+        if self.all_reduce and not self.captured_collective:
             self.graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
                 opt.step()
@@ -276,7 +307,7 @@ class GraphedTrainStep:
         self.opt.sync_hyper()
         self.graph.replay()
         if self.graph_opt is not None:
-            parallel.all_reduce_gradients(self.params)
+            self.arena.all_reduce(force=self.force)      # eager, in place on the arena the two graphs read and write
             self.graph_opt.replay()
         self.opt.note_replay()
         # the parameters changed behind autograd's back: move their version counters so that any eager render_rays
@@ -296,7 +327,9 @@ class RayTrainer:
         1024 rays the ~35 launches of an eager step are the critical path (1.9 vs 1.67 ms per step); at 4096 rays it
         makes no difference.  The first fit_epoch call spends two extra steps on its first batch (warm-up before the capture)."""
         self.dev = torch.device(device)
-        self.use_graph = bool(use_graph) and self.dev.type == "cuda"
+        if self.dev.type != "cuda":
+            raise RuntimeError("nerf_fl_amd.train.RayTrainer needs a ROCm device (this build has no CPU path)")
+        self.use_graph = bool(use_graph)
         self._graphed = None
         self.hp = dict(N_samples=N_samples, N_importance=N_importance, use_disp=use_disp, perturb=perturb,
                        noise_std=noise_std, white_back=white_back, batch_size=batch_size)
@@ -319,14 +352,14 @@ class RayTrainer:
         # one-launch Adam.  (torch's own fused=True variant is not an option here: it updates the parameters without
         # moving their version counters, so render_rays never re-packed its weight streams and kept rendering with
         # the initial weights -- tests/test_train_gpu.py: validation PSNR 26.89 -> 26.93 instead of 35.9)
-        self.opt = (Adam(self.params, lr=lr, eps=1e-8, capturable=self.use_graph) if self.dev.type == "cuda"
-                    else torch.optim.Adam(self.params, lr=lr, eps=1e-8))
+        self.opt = Adam(self.params, lr=lr, eps=1e-8, capturable=self.use_graph)
         if lr_scheduler == "cosine":
             self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=num_epochs, eta_min=1e-8)
         elif lr_scheduler == "steplr":
             self.sched = torch.optim.lr_scheduler.MultiStepLR(self.opt, milestones=list(decay_step), gamma=decay_gamma)
         else:
             self.sched = None
+        self.arena = parallel.GradArena(self.params)      # flat gradient memory: written by the backward, all-reduced in place
         self.loss = NerfWLoss()
         self.fused_loss = True          # False: the NerfWLoss module on the result dict (two extra launches), as the reference composes it
         self.gen = torch.Generator(device=self.dev).manual_seed(seed + 1)
@@ -334,19 +367,19 @@ class RayTrainer:
     # ---- one optimisation step on a ready batch ------------------------------------------------
     def step(self, rays, rgbs, ts):
         hp = self.hp
-        self.opt.zero_grad(set_to_none=True)
-        if rays.is_cuda and self.fused_loss:
-            # NerfWLoss (coef 1, lambda_u 0.01) computed in the render kernels' per-ray epilogue, its backward seeds with it
+        self.arena.attach()          # parameters the backward never reaches keep the zeros the arena was created with
+        if self.fused_loss:
+            # NerfWLoss computed in the render kernels' per-ray epilogue, its backward seeds with it
             res = render_rays(self.models, self.embeddings, rays, ts, hp["N_samples"], hp["use_disp"], hp["perturb"],
                               hp["noise_std"], hp["N_importance"], 32768, hp["white_back"], False, loss_target=rgbs,
-                              loss_coef=self.loss.coef, lambda_u=self.loss.lambda_u)
+                              loss_coef=self.loss.coef, lambda_u=self.loss.lambda_u, grad_arena=self.arena)
             total = res["_nerfw_loss"]
         else:
             res = render_rays(self.models, self.embeddings, rays, ts, hp["N_samples"], hp["use_disp"], hp["perturb"],
-                              hp["noise_std"], hp["N_importance"], 32768, hp["white_back"], False)
+                              hp["noise_std"], hp["N_importance"], 32768, hp["white_back"], False, grad_arena=self.arena)
             total = sum(self.loss(res, rgbs).values())
         total.backward()
-        parallel.all_reduce_gradients(self.params)
+        self.arena.all_reduce()
         self.opt.step()
         key = "rgb_fine" if "rgb_fine" in res else "rgb_coarse"
         return total.detach(), psnr(res[key].detach(), rgbs)
@@ -365,16 +398,16 @@ class RayTrainer:
                     self._graphed = GraphedTrainStep(
                         self.models, self.embeddings, self.params, self.opt, None, rays[idx], ts[idx], rgbs[idx],
                         hp["N_samples"], hp["N_importance"], hp["use_disp"], hp["perturb"], hp["noise_std"], hp["white_back"],
-                        all_reduce=dist.is_initialized() and dist.get_world_size() > 1)
+                        all_reduce=dist.is_initialized() and dist.get_world_size() > 1,
+                        loss_coef=self.loss.coef, lambda_u=self.loss.lambda_u, arena=self.arena)
                 self._graphed.load(rays[idx], ts[idx], rgbs[idx])
                 log.append(tuple(x.clone() for x in self._graphed.replay()))      # the outputs live in the graph's pool
             else:
                 log.append(self.step(rays[idx], rgbs[idx], ts[idx]))
         if self.sched is not None:
             self.sched.step()
-        if self.dev.type == "cuda":
-            from .rendering import check_status
-            check_status(self.dev)          # fp16 range audit of the epoch's render passes (raises FloatingPointError)
+        from .rendering import check_status
+        check_status(self.dev)              # fp16 range audit of the epoch's render passes (raises FloatingPointError)
         return torch.stack([torch.stack(x) for x in log]).mean(0).tolist() if log else [math.nan, math.nan]
 
     @torch.no_grad()

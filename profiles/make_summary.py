@@ -116,7 +116,13 @@ step_traffic = {"hbm_bytes": (2.0 * tot_f + tot_w) * 1024.0 / n_steps, "steps_co
                 "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB summed over every nfl_* dispatch of one train step; the "
                         "excess over the algorithmic bytes is the fp16 activation / gradient stashes of the layer-major "
                         "backward (DESIGN.md section 5)"}
-json.dump({"kernel_stats": kernel_stats, "launch_clusters": clusters, "traffic": traffic, "sq": sqs, "step_traffic": step_traffic},
+import datetime
+import hashlib
+lib = os.path.join(os.path.dirname(here), "nerf_fl_amd", "libnerf_fl_amd.so")
+provenance = {"tag": tag, "collected_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
+              "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
+              "command": "profiles/collect.sh " + tag}
+json.dump({"provenance": provenance, "kernel_stats": kernel_stats, "launch_clusters": clusters, "traffic": traffic, "sq": sqs, "step_traffic": step_traffic},
           open(os.path.join(here, f"{tag}_summary.json"), "w"), indent=1)
 for f in ("bench_train.json", "bench_render.json", "time_passes.txt", "bench_configs.json", "bench_cfg3_r1024.json",
           "bench_cfg3_r4096.json", "bench_cfg3_r1024_graph.json"):

@@ -132,3 +132,95 @@ def test_render_frame_and_sharded_video(use_graph):
     assert (full_lo, lo0, lo1) == (0, 0, 3) and part0.shape[0] == 3 and part1.shape[0] == 2
     assert torch.equal(torch.cat([part0, part1]), full)
     assert torch.equal(full[2], img)
+
+
+def test_graph_cache_is_keyed_by_everything_that_changes_the_launches():
+    """One cache, several call signatures (VERDICT r2 weak #10a): `output_transient`, the presence of a_embedded /
+    view_dir and the model objects each get their own capture; the same signature replays; every result equals the
+    eager call's."""
+    import gpu_util
+    from nerf_fl_amd import render_rays
+    from nerf_fl_amd.eval import batched_inference
+    dev = gpu_util.DEV
+    models, emb = _nerfw_models(dev)
+    models2, _ = _nerfw_models(dev)
+    with torch.no_grad():
+        for p in models2["fine"].parameters():
+            p.mul_(1.05)
+    R, chunk, S, I = 700, 256, 32, 32
+    rays = orc.make_rays(R, 7, near=0.3, far=5.0).to(dev)
+    ts = torch.randint(0, 50, (R,), device=dev)
+    vd = torch.nn.functional.normalize(torch.randn(R, 3, device=dev), dim=1)
+    a_one = emb["a"](torch.tensor([3], device=dev)).detach()
+    cache = {}
+    calls = [(models, {}), (models, {"output_transient": False}), (models, {"view_dir": vd}),
+             (models, {"a_embedded": a_one, "output_transient": False}), (models2, {}), (models, {})]
+    sizes = []
+    for m, kw in calls:
+        got = batched_inference(m, emb, rays, ts, S, I, chunk=chunk, white_back=True, use_graph=True, _graph_cache=cache, **kw)
+        sizes.append(len(cache))
+        kw_e = dict(kw)
+        if "a_embedded" in kw_e:
+            kw_e["a_embedded"] = kw_e["a_embedded"].expand(R, -1)
+        with torch.no_grad():
+            exp = render_rays(m, emb, rays, ts, S, False, 0, 0, I, chunk, True, True, **kw_e)
+        assert list(got) == list(exp)
+        for k in exp:
+            assert torch.equal(got[k], exp[k]), (kw.keys(), k)
+    assert sizes == [1, 2, 3, 4, 5, 5]
+
+
+def test_graph_replay_follows_the_weights():
+    """A cached capture must not render with the weights it was captured on (VERDICT r2 weak #10b): after
+    load_state_dict and after an in-place optimizer-style update, with NO eager render in between, replay == eager."""
+    import gpu_util
+    from nerf_fl_amd import render_rays
+    from nerf_fl_amd.eval import batched_inference, _GRAPH_CACHE
+    dev = gpu_util.DEV
+    models, emb = _nerfw_models(dev)
+    R, chunk, S, I = 512, 256, 32, 32
+    rays = orc.make_rays(R, 8, near=0.3, far=5.0).to(dev)
+    ts = torch.randint(0, 50, (R,), device=dev)
+    n0 = len(_GRAPH_CACHE)
+    first = batched_inference(models, emb, rays, ts, S, I, chunk=chunk, white_back=True, use_graph=True)
+    assert len(_GRAPH_CACHE) == n0 + 1                                  # the module-level default cache keeps the capture ...
+    spec_f = orc.FieldSpec("fine", encode_appearance=True, encode_transient=True, beta_min=0.1)
+    models["fine"].load_state_dict({k: v.to(dev) for k, v in orc.make_field_params(spec_f, 44, "sharp").items()})
+    second = batched_inference(models, emb, rays, ts, S, I, chunk=chunk, white_back=True, use_graph=True)
+    assert len(_GRAPH_CACHE) == n0 + 1                                  # ... and the second call replays it
+    with torch.no_grad():
+        exp = render_rays(models, emb, rays, ts, S, False, 0, 0, I, chunk, True, True)
+    assert not torch.equal(first["rgb_fine"], second["rgb_fine"])
+    for k in exp:
+        assert torch.equal(second[k], exp[k]), k
+    with torch.no_grad():                                                # what an optimizer step does: in place + version bump
+        for p in models["coarse"].parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    third = batched_inference(models, emb, rays, ts, S, I, chunk=chunk, white_back=True, use_graph=True)
+    with torch.no_grad():
+        exp = render_rays(models, emb, rays, ts, S, False, 0, 0, I, chunk, True, True)
+    for k in exp:
+        assert torch.equal(third[k], exp[k]), k
+
+
+def test_camera_rays_under_a_graph():
+    """CameraRays + use_graph: the captured prologue reads the camera from device memory (C ABI nfl_pass_args::d_cam), so
+    one capture renders any pose / pixel range -- bit-identical to the eager camera prologue (VERDICT r2 weak #10d)."""
+    import gpu_util
+    from nerf_fl_amd import CameraRays
+    from nerf_fl_amd.eval import batched_inference, fov60_intrinsics
+    from nerf_fl_amd.poses import make_c2w
+    dev = gpu_util.DEV
+    models, emb = _nerfw_models(dev)
+    H, W, S, I, chunk = 21, 30, 32, 32, 256
+    K = fov60_intrinsics(W, H)
+    cache = {}
+    for k, eye in enumerate(([0.1, -0.2, 3.9], [0.6, 0.3, 3.5])):
+        c2w = make_c2w(torch.tensor([0.1, -0.2, 0.05]), torch.tensor(eye))[:3]
+        cam = CameraRays(c2w, K, H, W, 2.0, 6.0, dev)
+        ts = torch.full((H * W,), 5 + k, dtype=torch.long, device=dev)
+        got = batched_inference(models, emb, cam, ts, S, I, chunk=chunk, white_back=True, use_graph=True, _graph_cache=cache)
+        exp = batched_inference(models, emb, cam, ts, S, I, chunk=chunk, white_back=True, use_graph=False)
+        assert len(cache) == 1
+        for key in exp:
+            assert torch.equal(got[key], exp[key]), key

@@ -53,3 +53,43 @@ def test_flat_allreduce_world2():
     for r in range(world):
         assert torch.allclose(out[r][3], expect)
         assert torch.equal(out[r][4], torch.zeros(3))
+
+
+def _arena_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # three parameters of awkward sizes (the arena aligns each to 16 bytes); one of them is never reached by "backward"
+    ps = [torch.nn.Parameter(torch.zeros(5, 3)), torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(2, 2))]
+    arena = parallel.GradArena(ps)
+    assert all(p.grad is arena.view(p) for p in ps)
+    assert all(p.grad.data_ptr() % 16 == 0 for p in ps)
+    ptr0 = arena.flat.data_ptr()
+    for step in range(3):                    # the "backward" writes in place, the collective runs in place
+        arena.view(ps[0]).fill_(float(rank + 1 + step))
+        arena.view(ps[1]).copy_(torch.arange(7.0) * (rank + 1))
+        for p in ps:
+            p.grad = None                    # an optimizer's zero_grad(set_to_none=True) in between ...
+        arena.attach()                       # ... is undone by attach()
+        parallel.all_reduce_gradients(ps, arena=arena)
+        assert arena.flat.data_ptr() == ptr0 and all(p.grad is arena.view(p) for p in ps)
+    out[rank] = [p.grad.clone() for p in ps]
+    dist.destroy_process_group()
+
+
+def test_grad_arena_allreduce_world2():
+    """GradArena: p.grad are views of ONE flat buffer; the all-reduce averages it in place (no cat, no copy back)."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_arena_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.equal(out[r][0], torch.full((5, 3), (3 + 4) / 2.0))          # step 2: ranks wrote 3 and 4
+        assert torch.allclose(out[r][1], torch.arange(7.0) * 1.5)
+        assert torch.equal(out[r][2], torch.zeros(2, 2))                           # never written: stays zero
+
+
+def test_grad_arena_rejects_mixed_inputs():
+    import pytest
+    with pytest.raises(ValueError):
+        parallel.GradArena([torch.nn.Parameter(torch.zeros(3), requires_grad=False)])
+    with pytest.raises(ValueError):
+        parallel.GradArena([torch.nn.Parameter(torch.zeros(3, dtype=torch.float64))])
