@@ -332,6 +332,38 @@ def run_rank(args):
         n_sus = max(100, int(args.sustained_seconds / max(elapsed / args.steps, 1e-6)) + 1)
         sustained = event_timed(step, n_sus)
         sync()
+    # the same step with the three-product (fp32-class) MLP backward: the reference differentiates in fp32
+    # (train.py:158-174), the default backward here multiplies in fp16; this is the train-step figure at the reference's
+    # precision class, measured on the same batch right after the default one (same K / W)
+    fp32_class = None
+    if args.mode == "train" and args.precision == "f16x3" and args.backward == "f16" and not args.no_extras:
+        nerf_fl_amd.set_precision(backward="f16x3")
+        step3 = train_step
+        if args.graph:
+            graphed3 = GraphedTrainStep(models, emb, params, opt, loss_fn if args.unfused_loss else None, rays, ts, target,
+                                        N_SAMPLES, N_IMPORTANCE, white_back=white_back, all_reduce=dist is not None,
+                                        arena=arena, force_all_reduce=force)
+            step3 = graphed3.replay
+        for _ in range(args.warmup):
+            step3()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step3()
+        sync()
+        e3 = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([e3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e3 = float(t.item())
+        fp32_class = {"value": R * (N_SAMPLES + N_IMPORTANCE) * n_ranks * args.steps / e3, "ms_per_step": 1e3 * e3 / args.steps,
+                      "dtype": "f16x3 fwd + f16x3 bwd",
+                      "backward_arithmetic": "fp16 MFMA, weights / activations / gradients split hi+lo, 3 products, fp32 accumulate; "
+                                             "hi+lo activation and gradient stashes (2x the bytes); gradients returned in fp32"}
+        if args.sustained_seconds > 0:
+            fp32_class["sustained"] = event_timed(step3, max(100, int(args.sustained_seconds / max(e3 / args.steps, 1e-6)) + 1))
+            sync()
+        nerf_fl_amd.set_precision(backward="f16")
     sync_diff = None
     if dist is not None:
         # data parallelism keeps the replicas identical: same seeded weights, the same averaged gradients, the same Adam.
@@ -364,10 +396,12 @@ def run_rank(args):
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "sustained": sustained,
+        "value_fp32_class": None if fp32_class is None else fp32_class["value"],
+        "fp32_class": fp32_class,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": ("f16x3 fwd + f16 bwd" if args.mode == "train" else "f16x3") if args.precision == "f16x3" else "f16",
+        "dtype": (f"f16x3 fwd + {args.backward} bwd" if args.mode == "train" else "f16x3") if args.precision == "f16x3" else "f16",
         "data": "synthetic",
         "config": {"workload": f"{wl}; {R} rays/GPU, N_samples=64 + N_importance=64, perturb=1 noise_std=1; "
                                + ("train step: render_rays fwd + NerfWLoss + HIP backward + grad all-reduce + Adam + re-pack"
@@ -377,8 +411,10 @@ def run_rank(args):
                    "rays_per_gpu": R, "mode": args.mode, "precision": args.precision,
                    "forward_arithmetic": "fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate (f16x3)"
                                          if args.precision == "f16x3" else "fp16 MFMA, 1 product, fp32 accumulate",
-                   "backward_arithmetic": "fp16 MFMA, 1 product, fp32 accumulate, fp16 activation/gradient stashes "
-                                          "under a device-chosen power-of-two loss scale; gradients returned in fp32",
+                   "backward_arithmetic": ("fp16 MFMA, 1 product, fp32 accumulate, fp16 activation/gradient stashes "
+                                           "under a device-chosen power-of-two loss scale; gradients returned in fp32"
+                                           if args.backward == "f16" else
+                                           "fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate, hi+lo stashes (f16x3)"),
                    "mlp_evals_per_ray": N_SAMPLES + F, "hip_graph": bool(args.graph)},
     }
 

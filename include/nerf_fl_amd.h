@@ -162,7 +162,8 @@ typedef struct nfl_pass_args {
     int32_t sigma_only;         /* coarse pass at test_time (rendering.py:103-111,169)   */
     int32_t white_back;
     int32_t test_extras;        /* test_time on a transient pass: rgb/depth_fine_{static,transient} */
-    int32_t reserved;
+    int32_t stash_split;        /* with d_act_stash: 1 = write split (hi + lo) activation records for a backward in
+                                   NFL_PREC_F16X3 (size the stash with nfl_act_stash_bytes(..., NFL_PREC_F16X3)); 0 = hi only */
     /* outputs (any may be NULL = not wanted) */
     float* d_weights;           /* (R,n_samples)                                         */
     float* d_opacity;           /* (R)                                                   */
@@ -243,15 +244,21 @@ int nfl_gen_rays(const float* h_c2w, float fx, float fy, float cx, float cy, int
  *   mixed precision: fp16 MFMA with fp32 accumulation on activations stashed in fp16 and on
  *   gradients multiplied by a per-pass power-of-two LOSS SCALE, chosen on the device from
  *   max|head gradient| (d_gmax, written by nfl_composite_backward) so that fp16's range is
- *   used whatever the loss magnitude; the scale is divided out before anything is returned. */
-size_t nfl_act_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples);
-size_t nfl_grad_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples);
+ *   used whatever the loss magnitude; the scale is divided out before anything is returned.
+ *
+ *   bwd_prec selects the arithmetic of that MLP part: NFL_PREC_F16 (default: one fp16 product, gradients within a few 1e-3
+ *   of fp32 autograd) or NFL_PREC_F16X3 -- the forward's split-operand arithmetic (hi + lo weight fragments, activations
+ *   and gradients, three products: fp32-class, the precision class of the reference's autograd); the stashes then hold a
+ *   second, residual record per segment (twice the bytes), written by a forward pass with nfl_pass_args::stash_split = 1.
+ *   One value must be used for the stash sizes, the forward pass, the dgrad plan / stream and nfl_mlp_wgrad of a step. */
+size_t nfl_act_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples, int32_t bwd_prec);
+size_t nfl_grad_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples, int32_t bwd_prec);
 /* dgrad plan / packed stream (transposed weights, fp16); same calling pattern as
  * nfl_plan_build / nfl_pack_field (pack with nfl_pack_field using these plans). */
 /* rays_grad != 0: the stream also carries the tiles needed for the gradient w.r.t. the rays
  * (learnable poses, reference models/poses.py + train.py:86-98). */
-int    nfl_bwd_plan_build(const nfl_field_desc* desc, int32_t rays_grad, void* h_plan, size_t bytes);
-size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc, int32_t rays_grad);
+int    nfl_bwd_plan_build(const nfl_field_desc* desc, int32_t rays_grad, int32_t bwd_prec, void* h_plan, size_t bytes);
+size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc, int32_t rays_grad, int32_t bwd_prec);
 
 typedef struct nfl_compbwd_args {
     const float* d_field_raw;       /* (R*N,9) from the forward pass                       */
@@ -322,8 +329,8 @@ int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, v
  * weight[NFL_P_T0] are read).  grads->bias[NFL_P_DIR] (and [NFL_P_T0]) must be given when any composed gradient is. */
 size_t nfl_wgrad_scratch_bytes(void);
 int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
-                  const float* d_gmax, int32_t n_rays, int32_t n_samples, const nfl_field_params* params,
-                  float* d_scratch, const nfl_field_grads* grads, void* stream);
+                  const float* d_gmax, int32_t n_rays, int32_t n_samples, int32_t bwd_prec,
+                  const nfl_field_params* params, float* d_scratch, const nfl_field_grads* grads, void* stream);
 
 /* ---- optimiser step (reference utils/__init__.py:30-32: torch.optim.Adam(lr, eps=1e-8), no weight decay, no
  * amsgrad) over up to NFL_ADAM_MAX_TENSORS fp32 tensors in one launch.  `step` is the 1-based count of this update

@@ -66,7 +66,7 @@ class PassArgs(C.Structure):
         ("d_noise", C.c_void_p), ("noise_std", C.c_float),
         ("d_a_emb", C.c_void_p), ("d_t_emb", C.c_void_p),
         ("sigma_only", C.c_int32), ("white_back", C.c_int32),
-        ("test_extras", C.c_int32), ("reserved", C.c_int32),
+        ("test_extras", C.c_int32), ("stash_split", C.c_int32),
         ("d_weights", C.c_void_p), ("d_opacity", C.c_void_p), ("d_rgb", C.c_void_p), ("d_depth", C.c_void_p),
         ("d_transient_sigmas", C.c_void_p), ("d_beta", C.c_void_p),
         ("d_rgb_static", C.c_void_p), ("d_rgb_transient", C.c_void_p),
@@ -144,16 +144,16 @@ SYMBOLS = [
     ("nfl_posenc", C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("nfl_gen_rays", C.c_int, [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_int64,
                                C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
-    ("nfl_act_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
-    ("nfl_grad_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
-    ("nfl_bwd_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),
-    ("nfl_bwd_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32]),
+    ("nfl_act_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32, C.c_int32]),
+    ("nfl_grad_stash_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32, C.c_int32]),
+    ("nfl_bwd_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    ("nfl_bwd_packed_bytes", C.c_size_t, [C.POINTER(FieldDesc), C.c_int32, C.c_int32]),
     ("nfl_composite_backward", C.c_int, [C.POINTER(CompBwdArgs), C.c_void_p]),
     ("nfl_mlp_dgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(DgradArgs), C.c_void_p]),
     ("nfl_wgrad_plan_bytes", C.c_size_t, []),
     ("nfl_wgrad_plan_build", C.c_int, [C.POINTER(FieldDesc), C.c_int32, C.c_void_p, C.c_size_t]),
     ("nfl_wgrad_scratch_bytes", C.c_size_t, []),
-    ("nfl_mlp_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+    ("nfl_mlp_wgrad", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                 C.POINTER(FieldParams), C.c_void_p, C.POINTER(FieldGrads), C.c_void_p]),
     ("nfl_adam_step", C.c_int, [C.POINTER(AdamTensors), C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                 C.c_void_p]),

@@ -37,24 +37,26 @@ size_t nfl_param_count(const nfl_field_desc* d) {
 static size_t n_segments(int32_t n_rays, int32_t n_samples) {
     return (size_t)n_rays * (size_t)((n_samples + 31) / 32);
 }
-size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples) {
-    if (!d || n_rays < 0 || n_samples < 1) return 0;
+size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples, int32_t bwd_prec) {
+    if (!d || n_rays < 0 || n_samples < 1 || (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3)) return 0;
     const int nkp = (6 * d->n_emb_xyz + 3 + 15) / 16;
-    // records + tail pad for 2-k-step tile reads, then the relu-mask words
-    return nfl_msk_offset(n_segments(n_rays, n_samples), nkp) + n_segments(n_rays, n_samples) * NFL_MSK_WORDS * 256;
+    const int mult = bwd_prec == NFL_PREC_F16X3 ? 2 : 1;
+    // records (hi, with a three-product backward + lo) + tail pad for 2-k-step tile reads, then the relu-mask words
+    return nfl_msk_offset(n_segments(n_rays, n_samples), nkp, mult) + n_segments(n_rays, n_samples) * NFL_MSK_WORDS * 256;
 }
-size_t nfl_grad_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples) {
-    if (!d || n_rays < 0 || n_samples < 1) return 0;
-    return (n_segments(n_rays, n_samples) + 1) * NFL_GRD_SLOTS * 1024 + 4096;   // + one scratch record for padded segments
+size_t nfl_grad_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples, int32_t bwd_prec) {
+    if (!d || n_rays < 0 || n_samples < 1 || (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3)) return 0;
+    const int mult = bwd_prec == NFL_PREC_F16X3 ? 2 : 1;
+    return (n_segments(n_rays, n_samples) + 1) * NFL_GRD_SLOTS * mult * 1024 + 4096;   // + one scratch record for padded segments
 }
-int nfl_bwd_plan_build(const nfl_field_desc* desc, int32_t rays_grad, void* h_plan, size_t bytes) {
+int nfl_bwd_plan_build(const nfl_field_desc* desc, int32_t rays_grad, int32_t bwd_prec, void* h_plan, size_t bytes) {
     if (!h_plan) return NFL_EINVAL;
     if (bytes < sizeof(NflPlan)) return NFL_ESMALL;
-    return nfl_plan_fill_bwd(desc, rays_grad, static_cast<NflPlan*>(h_plan));
+    return nfl_plan_fill_bwd(desc, rays_grad, bwd_prec, static_cast<NflPlan*>(h_plan));
 }
-size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc, int32_t rays_grad) {
+size_t nfl_bwd_packed_bytes(const nfl_field_desc* desc, int32_t rays_grad, int32_t bwd_prec) {
     NflPlan p;
-    if (nfl_plan_fill_bwd(desc, rays_grad, &p) != NFL_OK) return 0;
+    if (nfl_plan_fill_bwd(desc, rays_grad, bwd_prec, &p) != NFL_OK) return 0;
     return (size_t)p.packed_bytes;
 }
 

@@ -20,10 +20,14 @@
 // reduced over the samples of the ray with wave shuffles and accumulated with fp32 atomics.
 #include "nfl_render_impl.h"
 
-// Two 32-sample segments (column blocks) per wave: with single-product fp16 a row tile is only 16 MFMAs per
+// Single-product kernel (NP = 1): two 32-sample segments (column blocks) per wave -- a row tile is only 16 MFMAs per
 // column block, so the per-tile fixed costs (barrier, weight DMA, LDS reads of the A fragments) are shared by
 // 64 samples; the register file holds it because the walk needs only TWO 16-k-step operand sets (P, Q below).
-#define DG_NCB 2
+// Three-product kernel (NP = 2: hi + lo weight fragments and hi + lo gradients, W_lo d_hi + W_hi d_lo + W_hi d_hi, the
+// forward's f16x3 arithmetic; opt-in, NFL_PREC_F16X3 backward): the operand sets are twice as large, so one segment
+// per wave, and a chunk of the stream is one row tile (two would not fit a ring slot).
+#define DG_NCB(NP) ((NP) == 1 ? 2 : 1)
+#define DG_TPC(NP) ((NP) == 1 ? 2 : 1)
 
 struct DgradArgs {
     const NflPlan* plan;
@@ -43,12 +47,12 @@ NFL_DEV NflDgKArgs nfl_dg_kargs() {
     return p;
 }
 
-template <int NFX>
+template <int NFX, int NP_>
 struct NflDgradCfg {
-    static constexpr int NP = 1, NCB = DG_NCB;
+    static constexpr int NP = NP_, NCB = DG_NCB(NP_), TPC = DG_TPC(NP_);
     static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
-    static constexpr int KSB = 1024;
-    static constexpr int MAXKS = 2 * 17;                 // two row tiles per chunk (one barrier per pair of tiles)
+    static constexpr int KSB = 1024 * NP;
+    static constexpr int MAXKS = TPC * 17;               // row tiles per chunk (NP 1: one barrier per pair of tiles)
     static constexpr int WBYTES = MAXKS * KSB;
     static constexpr int AUXB = 4 * NCB * 1024;
     static constexpr int SLOT = WBYTES + AUXB;
@@ -196,14 +200,15 @@ NFL_DEV void dg_zero(f16v (&acc)[NCB]) {
 
 // epilogue of a dgrad tile, cut into 8 pair-ops: relu mask (sign of the stashed activation),
 // fp16 into the next operand set and into the gradient stash
-template <bool MASK, int NOUT, int NCB>
+template <bool MASK, int NOUT, int NCB, int NP>
 struct DgEpi {
     const f16v (&acc)[NCB];
     const unsigned (&mk)[NCB];
-    h8 (&out)[NOUT][NCB][1];
+    h8 (&out)[NOUT][NCB][NP];
     const int ks;
     char* const (&gst)[NCB];
     const int slot;
+    static constexpr int LO = NP == 2 ? NFL_GRD_SLOTS * 1024 : 0;     // the residual record follows the hi record (nfl_plan.h)
 
     template <int OP>
     NFL_DEV void pair() {
@@ -211,15 +216,24 @@ struct DgEpi {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
-            unsigned hi = nfl_pack2<_Float16>(x0, x1);
+            unsigned hi, lo = 0u;
+            if constexpr (NP == 2) {
+                float l0, l1;
+                hi = nfl_split_pair<_Float16>(x0, x1, l0, l1);
+                lo = nfl_pack2<_Float16>(l0, l1);
+            } else {
+                hi = nfl_pack2<_Float16>(x0, x1);
+            }
             if (MASK) {
                 // the forward's mask word has the pair's two predicates at bits 2*OP and 16 + 2*OP: shifted down
                 // they are 0/1 per half, and an integer multiply of the gradient's fp16 bits by them masks exactly
                 // (inline asm: LLVM rewrites the C form into compares and selects)
                 const unsigned on = (mk[cb] >> (2 * OP)) & 0x00010001u;
                 asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(hi) : "v"(hi), "v"(on));
+                if constexpr (NP == 2) asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(lo) : "v"(lo), "v"(on));
             }
             reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][0])[j / 2] = hi;
+            if constexpr (NP == 2) reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][NP - 1])[j / 2] = lo;
             // both stash stores of the tile are issued at its last pair-op, i.e. after every DMA piece of the
             // tile they ride in: the ring's counted vmcnt wait can then leave TWO tiles of stores outstanding
             // (the HBM write acknowledgement takes longer than one 16-MFMA row tile)
@@ -227,6 +241,10 @@ struct DgEpi {
                 // streaming stores: the 2.6 GB of stash must not evict the weight stream from L2
                 __builtin_nontemporal_store(out[ks][cb][0], reinterpret_cast<h8*>(gst[cb] + slot * 1024));
                 __builtin_nontemporal_store(out[ks + 1][cb][0], reinterpret_cast<h8*>(gst[cb] + (slot + 1) * 1024));
+                if constexpr (NP == 2) {
+                    __builtin_nontemporal_store(out[ks][cb][NP - 1], reinterpret_cast<h8*>(gst[cb] + LO + slot * 1024));
+                    __builtin_nontemporal_store(out[ks + 1][cb][NP - 1], reinterpret_cast<h8*>(gst[cb] + LO + (slot + 1) * 1024));
+                }
             }
         }
     }
@@ -247,12 +265,13 @@ struct DgEpi {
 
 // NRT transposed row tiles (two per chunk) with up to three K segments.  TS: k-steps a tile occupies in the stream
 // (more than the NK it reads when a pass leaves out the transient head's segment of the d(feat) tiles)
-template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int TS = NKA + NKB + NKC, int NA, int NB, int NC, int NOUT, class Ring>
+template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int NP, int TS = NKA + NKB + NKC, int NA, int NB, int NC, int NOUT, class Ring>
 NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
-                      const h8 (&inA)[NA][NCB][1], int ksA, const h8 (&inB)[NB][NCB][1], int ksB,
-                      const h8 (&inC)[NC][NCB][1], int ksC,
-                      h8 (&out)[NOUT][NCB][1], int out_ks0, char* const (&gst)[NCB], int slot0) {
+                      const h8 (&inA)[NA][NCB][NP], int ksA, const h8 (&inB)[NB][NCB][NP], int ksB,
+                      const h8 (&inC)[NC][NCB][NP], int ksC,
+                      h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&gst)[NCB], int slot0) {
     constexpr int NK = NKA + NKB + NKC;
+    constexpr int TPC = DG_TPC(NP);
     f16v acc[2][NCB];
     unsigned mk[2][NCB];
     unsigned mkq[NCB][4];       // the four mask words of the current group of tiles (arrive with its first tile)
@@ -266,8 +285,8 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
     const char* wl = nullptr;
     nfl_static_for<0, NRT>([&](auto I) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
-        constexpr int P0 = (i & 1) * TS;                 // k-step of this tile inside its two-tile chunk
-        if constexpr ((i & 1) == 0) wl = ring.consume();
+        constexpr int P0 = (i % TPC) * TS;               // k-step of this tile inside its chunk
+        if constexpr (i % TPC == 0) wl = ring.consume();
         dg_zero<NCB>(acc[i & 1]);
         if (MASK) {      // the slot is recycled at the next consume(): take the masks now
             if constexpr ((i & 3) == 0) {
@@ -282,25 +301,26 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
             for (int cb = 0; cb < NCB; ++cb) mk[i & 1][cb] = mkq[cb][i & 3];
         }
         if constexpr (i > 0) {
-            DgEpi<MASK, NOUT, NCB> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
-            nfl_tile<1, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
-            ring.note(2 * NCB);          // the epilogue's stash stores, issued at the tile's last k-step
+            DgEpi<MASK, NOUT, NCB, NP> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
+            nfl_tile<NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
+            ring.note(2 * NCB * NP);     // the epilogue's stash stores, issued at the tile's last k-step
         } else {
             NflNoEpi epi;
-            nfl_tile<1, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
+            nfl_tile<NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
         }
-        // pieces the pair's k-loops did not get to (piece P0 + k is issued at k-step k of its tile)
-        if constexpr ((i & 1) == 0) ring.template pieces<NK, TS>();
+        // pieces the chunk's k-loops did not get to (piece P0 + k is issued at k-step k of its tile)
+        if constexpr (TPC == 1) ring.template pieces<NK, Ring::MAXP>();
+        else if constexpr ((i & 1) == 0) ring.template pieces<NK, TS>();
         else ring.template pieces<TS + NK, Ring::MAXP>();
     });
-    DgEpi<MASK, NOUT, NCB> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
+    DgEpi<MASK, NOUT, NCB, NP> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
     last.all();
-    ring.note(2 * NCB);
+    ring.note(2 * NCB * NP);
 }
 
 // one tile whose rows are latent inputs: sum over the 32 samples of each segment, add to its ray's gradient
-template <int NK, int NCB, int NIN, class Ring>
-NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, float* const (&dst)[NCB], int nvalid, int h, int c,
+template <int NK, int NCB, int NP, int NIN, class Ring>
+NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, float* const (&dst)[NCB], int nvalid, int h, int c,
                             float inv_scale) {
     const char* wl = ring.consume();
     f16v acc[NCB];
@@ -309,7 +329,7 @@ NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, fl
         return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile<1, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile<NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -325,8 +345,8 @@ NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, fl
 // an N-frequency encoding): chain the feature gradients through d/dx [x, w_k sin(2^k x), w_k cos(2^k x)]
 // into the gradient of the 3 encoded coordinates of this lane's sample (partial: the two lane halves
 // hold different rows and are summed by the caller).
-template <int N, int T, int NK, int NCB, int NIN, class Ring>
-NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, int h,
+template <int N, int T, int NK, int NCB, int NP, int NIN, class Ring>
+NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, int h,
                         const float (&th)[NCB][3], const float (&tl)[NCB][3], const float* pw,
                         float (&g)[NCB][3]) {
     const char* wl = ring.consume();
@@ -336,7 +356,7 @@ NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, int h,
         return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile<1, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile<NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -367,10 +387,12 @@ NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][1], int ks0, int h,
         }
 }
 
-template <int NFX>
+template <int NFX, int NP>
 __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
-    using C = NflDgradCfg<NFX>;
+    using C = NflDgradCfg<NFX, NP>;
     constexpr int NKP = C::NKP, WB = C::WBYTES, NCB = C::NCB;
+    constexpr int GREC = NFL_GRD_SLOTS * NP;                   // slots of a segment's gradient record: hi (+ lo)
+    constexpr int GLO = NP == 2 ? NFL_GRD_SLOTS * 1024 : 0;    // byte offset of the residual record
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int* const chk_lds = reinterpret_cast<int*>(smem);
     int* const aux_lds = chk_lds + NFL_MAX_CHUNKS + 8;
@@ -405,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     ring.chunk_off = chk_lds;
     ring.chunk_aux = aux_lds;
     ring.lds = smem + C::LDS_TAB;
-    ring.aux_src = a.d_act_stash + nfl_msk_offset((size_t)A.n_seg_total, NKP);
+    ring.aux_src = a.d_act_stash + nfl_msk_offset((size_t)A.n_seg_total, NKP, NP);      // split activation records with NP 2
     ring.seg_stride = (size_t)NFL_MSK_WORDS * 256;      // 21 groups of 1 KiB
     ring.n_chunks = A.n_chunks;
     ring.c_start = A.c_start;
@@ -438,7 +460,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             const int i = (gg % SPR) * 32 + c;
             const bool ok = seg_ok[cb] && i < N;
             // padded segments (zero gradients) write to a scratch record past the end: no branch in the epilogue
-            gst[cb] = K->a.d_grad_stash + (size_t)(seg_ok[cb] ? ray0 * SPR + gg : K->n_seg_total) * NFL_GRD_SLOTS * 1024 + (2 * c + h) * 16;     // [sample][lane half][8] image, as the activation stash
+            gst[cb] = K->a.d_grad_stash + (size_t)(seg_ok[cb] ? ray0 * SPR + gg : K->n_seg_total) * GREC * 1024 + (2 * c + h) * 16;     // [sample][lane half][8] image, as the activation stash
             zs[cb] = 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) xth[cb][k] = xtl[cb][k] = dth[cb][k] = dtl[cb][k] = gx[cb][k] = gd[cb][k] = 0.f;
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         // this wave's mask words in a ring slot (wl carries lane * 16 = the lane's four words of a group)
         const int moff = wave * (1024 * NCB);
         // head gradients as natural-order B operands (k = 8h + j)
-        h8 dS[1][NCB][1], dC[1][NCB][1], dTs[1][NCB][1], dTc[1][NCB][1], dTb[1][NCB][1];
+        h8 dS[1][NCB][NP], dC[1][NCB][NP], dTs[1][NCB][NP], dTc[1][NCB][NP], dTb[1][NCB][NP];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const float vS[8] = {hg[cb][3], 0, 0, 0, 0, 0, 0, 0};
@@ -467,38 +489,38 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             const float vTs[8] = {hg[cb][7], 0, 0, 0, 0, 0, 0, 0};
             const float vTc[8] = {hg[cb][4], hg[cb][5], hg[cb][6], 0, 0, 0, 0, 0};
             const float vTb[8] = {hg[cb][8], 0, 0, 0, 0, 0, 0, 0};
-            nfl_split8<1>(vS, dS[0][cb]);
-            nfl_split8<1>(vC, dC[0][cb]);
-            nfl_split8<1>(vTs, dTs[0][cb]);
-            nfl_split8<1>(vTc, dTc[0][cb]);
-            nfl_split8<1>(vTb, dTb[0][cb]);
-            nfl_stash8(vS, gst[cb] + (NFL_GRD_HEADS + 0) * 1024);
-            nfl_stash8(vC, gst[cb] + (NFL_GRD_HEADS + 1) * 1024);
+            nfl_split8<NP>(vS, dS[0][cb]);
+            nfl_split8<NP>(vC, dC[0][cb]);
+            nfl_split8<NP>(vTs, dTs[0][cb]);
+            nfl_split8<NP>(vTc, dTc[0][cb]);
+            nfl_split8<NP>(vTb, dTb[0][cb]);
+            nfl_stash8<GLO>(vS, gst[cb] + (NFL_GRD_HEADS + 0) * 1024);
+            nfl_stash8<GLO>(vC, gst[cb] + (NFL_GRD_HEADS + 1) * 1024);
             if (K->use_t) {        // no weight-gradient job reads them otherwise
-                nfl_stash8(vTs, gst[cb] + (NFL_GRD_HEADS + 2) * 1024);
-                nfl_stash8(vTc, gst[cb] + (NFL_GRD_HEADS + 3) * 1024);
-                nfl_stash8(vTb, gst[cb] + (NFL_GRD_HEADS + 4) * 1024);
+                nfl_stash8<GLO>(vTs, gst[cb] + (NFL_GRD_HEADS + 2) * 1024);
+                nfl_stash8<GLO>(vTc, gst[cb] + (NFL_GRD_HEADS + 3) * 1024);
+                nfl_stash8<GLO>(vTb, gst[cb] + (NFL_GRD_HEADS + 4) * 1024);
             }
         }
         // Two operand sets of 16 k-steps are enough for the whole walk: the transient chain ping-pongs between
         // the halves of Q, d(dir hidden) lands in Q[0..8) next to dg1 in Q[8..16), d(h8) -- straight from those two through
         // the folded W_dir' / W_t0' -- in P, then the trunk alternates Q, P, Q, ...
-        h8 P[16][NCB][1], Q[16][NCB][1];
+        h8 P[16][NCB][NP], Q[16][NCB][NP];
         K = nfl_dg_kargs();
         if (K->use_t) {
-            dg_tiles<WB, true, 4, 1, 1, 1, NCB>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
+            dg_tiles<WB, true, 4, 1, 1, 1, NCB, NP>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, NP>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
             float* gt[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const size_t row = K->a.d_latent_row ? (size_t)K->a.d_latent_row[ray[cb]] : (size_t)ray[cb];     // table row or ray
                 gt[cb] = (K->a.d_g_t_emb && seg_ok[cb]) ? K->a.d_g_t_emb + row * 16 : nullptr;
             }
-            dg_latent_tile<8, NCB>(ring, Q, 8, gt, 16, h, c, inv_scale);
+            dg_latent_tile<8, NCB, NP>(ring, Q, 8, gt, 16, h, c, inv_scale);
         }
-        dg_tiles<WB, true, 4, 1, 0, 0, NCB>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
+        dg_tiles<WB, true, 4, 1, 0, 0, NCB, NP>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
         K = nfl_dg_kargs();
         if (K->has_a) {
             float* ga[NCB];
@@ -509,43 +531,46 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                 ga[cb] = (K->a.d_g_a_emb && seg_ok[cb]) ? K->a.d_g_a_emb + row * 48 : nullptr;
                 ga2[cb] = ga[cb] ? ga[cb] + 32 : nullptr;
             }
-            dg_latent_tile<8, NCB>(ring, Q, 0, ga, 32, h, c, inv_scale);
-            dg_latent_tile<8, NCB>(ring, Q, 0, ga2, 16, h, c, inv_scale);
+            dg_latent_tile<8, NCB, NP>(ring, Q, 0, ga, 32, h, c, inv_scale);
+            dg_latent_tile<8, NCB, NP>(ring, Q, 0, ga2, 16, h, c, inv_scale);
         }
         K = nfl_dg_kargs();
-        if (K->rays_tiles) dg_pe_tile<4, 0, 8, NCB>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
+        if (K->rays_tiles) dg_pe_tile<4, 0, 8, NCB, NP>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
         // d(h8) straight from the 128-wide head gradients: xyz_encoding_final is folded into W_dir' / W_t0' (nfl_plan.cpp),
         // so there are no d(feat) tiles; tile = [W_dir'^T: 8 k-steps | W_t0'^T: 8 (fields with a transient head) | W_sigma^T: 1]
         if (K->use_t) {
-            dg_tiles<WB, true, 8, 8, 8, 1, NCB>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB, NP>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
         } else if (K->has_t) {      // the stream carries the transient segment: multiply it by zeros
 #pragma unroll
             for (int ks = 8; ks < 16; ++ks)
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) Q[ks][cb][0][j] = (_Float16)0.f;
-            dg_tiles<WB, true, 8, 8, 8, 1, NCB>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+                    for (int j = 0; j < 8; ++j) {
+                        Q[ks][cb][0][j] = (_Float16)0.f;
+                        Q[ks][cb][NP - 1][j] = (_Float16)0.f;
+                    }
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB, NP>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
         } else {
-            dg_tiles<WB, true, 8, 8, 1, 0, NCB>(ring, moff, Q, 0, dS, 0, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 1, 0, NCB, NP>(ring, moff, Q, 0, dS, 0, dS, 0, P, 0, gst, NFL_GRD_D(8));
         }
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(7));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(6));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(5));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(4));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(7));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(6));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(5));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(4));
         K = nfl_dg_kargs();
         if (K->rays_tiles) {       // skip connection: delta_5 (still in Q) reaches the encoded position too
-            dg_pe_tile<NFX, 0, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 0, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
         }
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(3));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(2));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(1));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(3));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(2));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(1));
         if (K->rays_tiles) {
-            dg_pe_tile<NFX, 0, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 0, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
             if (K->a.d_g_rays) {
                 // x = o + d z ; the view direction is d itself (no caller passes view_dir with learnable poses)
 #pragma unroll
@@ -577,10 +602,11 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
 #endif
 }
 
-template <int NFX>
+template <int NFX, int NP>
 static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_packed, const nfl_dgrad_args* args,
                         hipStream_t stream) {
-    using C = NflDgradCfg<NFX>;
+    using C = NflDgradCfg<NFX, NP>;
+    constexpr int NCB_ = C::NCB;
     DgradArgs A;
     A.plan = static_cast<const NflPlan*>(d_plan);
     A.packed = static_cast<const char*>(d_packed);
@@ -598,19 +624,19 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int rpw = (args->n_rays + ncu - 1) / ncu;
-    const int rays_per_tile = 4 * DG_NCB / A.spr;
+    const int rays_per_tile = 4 * NCB_ / A.spr;
     if (rays_per_tile > 1) rpw = (rpw + rays_per_tile - 1) / rays_per_tile * rays_per_tile;
     if (rpw < 1) rpw = 1;
     A.rays_per_wg = rpw;
     const int grid = (args->n_rays + rpw - 1) / rpw;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_dgrad_kernel<NFX>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_dgrad_kernel<NFX, NP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
             return NFL_ENODEV;
         attr_set = true;
     }
-    hipLaunchKernelGGL((nfl_dgrad_kernel<NFX>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
+    hipLaunchKernelGGL((nfl_dgrad_kernel<NFX, NP>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }
 
@@ -622,7 +648,12 @@ extern "C" int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, con
     if (args->n_rays < 0 || args->n_samples < 1) return NFL_EINVAL;
     if (args->n_rays == 0) return NFL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hp->n_emb_xyz == 10) return launch_dgrad<10>(hp, d_bwd_plan, d_bwd_packed, args, s);
-    if (hp->n_emb_xyz == 15) return launch_dgrad<15>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->nsplit == 3) {          // three-product (fp32-class) backward: hi + lo fragments, split stashes
+        if (hp->n_emb_xyz == 10) return launch_dgrad<10, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+        if (hp->n_emb_xyz == 15) return launch_dgrad<15, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+        return NFL_EINVAL;
+    }
+    if (hp->n_emb_xyz == 10) return launch_dgrad<10, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->n_emb_xyz == 15) return launch_dgrad<15, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
     return NFL_EINVAL;
 }

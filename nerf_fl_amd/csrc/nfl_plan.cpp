@@ -115,9 +115,14 @@ static int check_desc(const nfl_field_desc* d) {
 // The dgrad stream (fp16): one transposed row tile per chunk, in the order the
 // backward kernel walks the network (heads first).  chunk_aux names the mask word (nfl_msk_*)
 // that holds the relu mask of that tile.
-extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan* p) {
+extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, int bwd_prec, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
-    common_init(d, NFL_PREC_F16, p);     // fp16, one product: gradients are loss-scaled (nfl_loss_scale_from_bits)
+    if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
+    // fp16 fragments, gradients loss-scaled (nfl_loss_scale_from_bits): one product, or hi + lo fragments for the
+    // three-product (fp32-class) backward.  The single-product kernel walks its tile groups two tiles per chunk (one
+    // barrier per pair); with hi + lo fragments a pair would not fit a ring slot, so that stream has one tile per chunk.
+    common_init(d, bwd_prec, p);
+    const bool pair = bwd_prec == NFL_PREC_F16;
     p->elem = 0;
     p->is_bwd = 1;
     const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
@@ -129,17 +134,17 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TSIGMA);
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_TRGB);
                 Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_TBETA);
-            }, t & 1);
+            }, pair && (t & 1));
         for (int j = 3; j >= 1; --j)
             for (int t = 0; t < 4; ++t)
                 b.ttile(32 * t, 32, nfl_msk_g(j) + t,
-                        [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0 + j); }, t & 1);
+                        [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0 + j); }, pair && (t & 1));
         b.ttile(W, d->n_tau, -1, [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0); });
     }
     const int first_static_chunk = p->n_chunks;      // the backward of a pass without the transient head starts here
     for (int t = 0; t < 4; ++t)
         b.ttile(32 * t, 32, nfl_msk_dirh() + t,
-                [&](NflRowTile& r) { Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_RGB); }, t & 1);
+                [&](NflRowTile& r) { Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_RGB); }, pair && (t & 1));
     if (p->has_a)
         for (int t = 0; t < 2; ++t)
             b.ttile(W + cd + 32 * t, t == 0 ? 32 : p->n_a - 32, -1,
@@ -152,12 +157,12 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, NflPlan
             Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR);
             if (p->has_t) Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0);
             Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_SIGMA);
-        }, t & 1);
+        }, pair && (t & 1));
     const int npe = (cx + 31) / 32;         // 32-row tiles covering the encoded position
     for (int l = 8; l >= 2; --l) {          // layer l (1-based) transposed -> gradient of h_{l-1}
         for (int t = 0; t < 8; ++t)
             b.ttile((l == 5 ? cx : 0) + 32 * t, 32, nfl_msk_h(l - 1) + t,
-                    [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); }, t & 1);
+                    [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); }, pair && (t & 1));
         if (l == 5 && rays_grad)            // skip connection: rows that multiply the encoded position
             for (int t = 0; t < npe; ++t)
                 b.ttile(32 * t, cx - 32 * t < 32 ? cx - 32 * t : 32, -1,

@@ -97,6 +97,11 @@ NFL_HD constexpr int nfl_act_dirh(int nkp) { return nkp + 133; }
 NFL_HD constexpr int nfl_act_tau(int nkp) { return nkp + 141; }
 NFL_HD constexpr int nfl_act_g(int nkp, int m) { return nkp + 142 + 8 * (m - 1); }   // m = 1..4
 NFL_HD constexpr int nfl_act_slots(int nkp) { return nkp + 174; }
+// Split (hi + lo) stashes of the fp32-class backward (NFL_BWD_F16X3): every record is followed by a second one of the
+// same layout holding the fp16 residuals, i.e. a segment's record is `mult` = 2 times as long and the residual of the
+// k-step in slot s sits nfl_act_slots(nkp) (NFL_GRD_SLOTS) slots behind it -- a compile-time offset for the writers,
+// a second base pointer for the weight-gradient GEMMs.
+NFL_HD constexpr int nfl_act_rec(int nkp, int mult) { return nfl_act_slots(nkp) * mult; }
 // relu masks, written by the training-mode forward behind the activation records (one 32-bit word per lane and
 // row tile of a relu layer: bit 2p = value 2p of the lane's 16 accumulators was positive, bit 16+2p = value 2p+1;
 // 256 B per wave and tile instead of the 2 KiB of fp16 activations the dgrad kernel would otherwise re-read;
@@ -107,7 +112,7 @@ NFL_HD constexpr int nfl_msk_dirh() { return 64; }
 NFL_HD constexpr int nfl_msk_g(int m) { return 68 + 4 * (m - 1); }   // m = 1..4
 #define NFL_MSK_WORDS 84
 // byte offset of the mask records inside the activation stash buffer (after the records and their 4 KiB tail pad)
-NFL_HD constexpr size_t nfl_msk_offset(size_t n_seg, int nkp) { return n_seg * (size_t)nfl_act_slots(nkp) * 1024 + 4096; }
+NFL_HD constexpr size_t nfl_msk_offset(size_t n_seg, int nkp, int mult = 1) { return n_seg * (size_t)nfl_act_rec(nkp, mult) * 1024 + 4096; }
 // pre-activation gradients, written by the dgrad kernel (d(feat) lives in registers only, see above):
 //   d1..d8 | ddirh | dg1..dg4 | head grads as natural k-steps: dsigma, drgb, dsigma_t, drgb_t, dbeta
 #define NFL_GRD_D(l) (16 * ((l) - 1))
@@ -137,7 +142,7 @@ extern "C" {
 struct nfl_field_desc;
 // returns 0 or a negative NFL_E* code
 int nfl_plan_fill(const struct nfl_field_desc* desc, int prec, struct NflPlan* plan);
-int nfl_plan_fill_bwd(const struct nfl_field_desc* desc, int rays_grad, struct NflPlan* plan);
+int nfl_plan_fill_bwd(const struct nfl_field_desc* desc, int rays_grad, int bwd_prec, struct NflPlan* plan);
 #ifdef __cplusplus
 }
 #endif

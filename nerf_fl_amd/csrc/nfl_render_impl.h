@@ -186,18 +186,29 @@ NFL_DEV void nfl_split8(const float (&v)[8], V8 (&dst)[NP]) {
     }
 }
 
-// 8 values -> fp16 -> this lane's 16 B of a stash k-step (dst already includes lane*16)
+// 8 values -> fp16 -> this lane's 16 B of a stash k-step (dst already includes lane*16); LO != 0: the fp16 residuals
+// x - fp16(x) go LO bytes behind (split stashes of the three-product backward, nfl_plan.h)
+template <int LO = 0>
 NFL_DEV void nfl_stash8(const float (&v)[8], char* dst) {
-    h8 t;
+    h8 t, tl;
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) reinterpret_cast<unsigned(&)[4]>(t)[j / 2] = nfl_pack2<_Float16>(v[j], v[j + 1]);
+    for (int j = 0; j < 8; j += 2) {
+        if constexpr (LO != 0) {
+            float l0, l1;
+            reinterpret_cast<unsigned(&)[4]>(t)[j / 2] = nfl_split_pair<_Float16>(v[j], v[j + 1], l0, l1);
+            reinterpret_cast<unsigned(&)[4]>(tl)[j / 2] = nfl_pack2<_Float16>(l0, l1);
+        } else {
+            reinterpret_cast<unsigned(&)[4]>(t)[j / 2] = nfl_pack2<_Float16>(v[j], v[j + 1]);
+        }
+    }
     NFL_STREAM_STORE(t, reinterpret_cast<h8*>(dst));
+    if constexpr (LO != 0) NFL_STREAM_STORE(tl, reinterpret_cast<h8*>(dst + LO));
 }
 
 // natural-order B operand of one k-step of a positional encoding: lane half h holds
 // features 16*ks + 8*h + j.  Both candidates are evaluated per-lane via selects so the
 // instruction stream is uniform.
-template <int N, int NP>
+template <int N, int NP, int LO = 0>
 NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th)[3], const float (&tl)[3],
                           const float* pw, h8 (&dst)[NP], char* stash = nullptr) {
     float v[8];
@@ -221,7 +232,10 @@ NFL_DEV void nfl_pe_kstep(int ks, int h, const float (&raw)[3], const float (&th
         }
     }
     nfl_split8<NP>(v, dst);
-    if (stash) nfl_stash8(v, stash);
+    if (stash) {        // the operand images ARE the stash (hi; with LO the residuals too)
+        NFL_STREAM_STORE(dst[0], reinterpret_cast<h8*>(stash));
+        if constexpr (LO != 0 && NP == 2) NFL_STREAM_STORE(dst[NP - 1], reinterpret_cast<h8*>(stash + LO));
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -436,7 +450,7 @@ struct NflNoEpi {
 // Epilogue of an accumulator tile -> the two k-steps (ks, ks+1) of the next layer's B operand
 // (and, in the training forward, the fp16 activation stash), cut into 8 pair-ops per column
 // block so it can be spread over the k-steps of the following tile.
-template <int NP, int NCB, bool RELU, bool STASH, int NOUT, int MSLOT>
+template <int NP, int NCB, bool RELU, bool STASH, int NOUT, int MSLOT, int LO = 0>
 struct NflActEpi {
     const f16v (&acc)[NCB];
     h8 (&out)[NOUT][NCB][NP];
@@ -448,6 +462,7 @@ struct NflActEpi {
     unsigned (&mq)[NCB][4];          // the words of the current group of four tiles: one dwordx4 store per group
     unsigned& ovf;                   // NflRing::ovf
     h8 tmp[NCB];
+    h8 tmpl[LO != 0 ? NCB : 1];      // residual halves for the split stash (LO: their byte offset behind the hi image)
     unsigned m32[NCB];
 
     template <int OP>
@@ -464,7 +479,12 @@ struct NflActEpi {
             if constexpr (NP == 2) {
                 float l0, l1;
                 hi = nfl_split_pair<_Float16>(x0, x1, l0, l1);
-                reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][NP - 1])[j / 2] = nfl_pack2<_Float16>(l0, l1);
+                const unsigned lo = nfl_pack2<_Float16>(l0, l1);
+                reinterpret_cast<unsigned(&)[4]>(out[ks + s][cb][NP - 1])[j / 2] = lo;
+                if constexpr (STASH && LO != 0) {
+                    reinterpret_cast<unsigned(&)[4]>(tmpl[cb])[j / 2] = lo;
+                    if (OP % 4 == 3) NFL_STREAM_STORE(tmpl[cb], reinterpret_cast<h8*>(stash[cb] + LO + (slot + s) * 1024));
+                }
             } else {
                 hi = nfl_pack2<_Float16>(x0, x1);
             }
@@ -511,14 +531,14 @@ struct NflActEpi {
 
 // A dense layer of NRT row tiles reading inA[ksA0..+NKA) then inB[ksB0..+NKB), TPC tiles per
 // ring chunk.  The epilogue of tile i-1 rides in the MFMA shadows of tile i.
-template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool STASH, int NINA, int NINB, int NOUT, class Ring>
+template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool STASH, int LO = 0, int NINA, int NINB, int NOUT, class Ring>
 NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
                        const h8 (&inA)[NINA][NCB][NP], int ksA0,
                        const h8 (&inB)[NINB][NCB][NP], int ksB0,
                        h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&stash)[NCB], int slot0,
                        char* const (&mstash)[NCB], int mw0) {
     constexpr int NK = NKA + NKB;
-    constexpr int NST = 2 * NCB;                         // activation-stash stores of one tile's epilogue (the mask
+    constexpr int NST = 2 * NCB * (LO != 0 ? 2 : 1);     // activation-stash stores of one tile's epilogue (the mask
                                                          // words go out once per four tiles: not counted, the wait is only stricter)
     unsigned mq[NCB][4];
     f16v acc[2][NCB];
@@ -535,7 +555,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         constexpr int frag0 = (i % TPC) * NK;
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         if constexpr (i > 0) {
-            NflActEpi<NP, NCB, RELU, STASH, NOUT, (i - 1) & 3> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1, mq, ring.ovf};
+            NflActEpi<NP, NCB, RELU, STASH, NOUT, (i - 1) & 3, LO> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1, mq, ring.ovf};
             nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
         } else {
             NflNoEpi epi;
@@ -544,7 +564,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         // pieces the k-loop of this chunk did not get to
         if (i % TPC == TPC - 1 || i == NRT - 1) ring.template pieces<((i % TPC) + 1) * NK, Ring::MAXP>();
     });
-    NflActEpi<NP, NCB, RELU, STASH, NOUT, (NRT - 1) & 3> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1, mq, ring.ovf};
+    NflActEpi<NP, NCB, RELU, STASH, NOUT, (NRT - 1) & 3, LO> last{acc[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), stash, slot0 + 2 * (NRT - 1), mstash, mw0 + NRT - 1, mq, ring.ovf};
     last.all();
     rt += NRT;
 }
@@ -657,13 +677,16 @@ NFL_DEV NflKCam nfl_kcam(NflKArgs K) {
 
 #define NFL_MODE_RENDER 0
 #define NFL_MODE_STASH 1      // render + fp16 activation stash for the backward
+#define NFL_MODE_STASH2 3     // as STASH, with split (hi + lo) activation records for the three-product backward
 #define NFL_MODE_EMBED 2      // NeRF.forward on already-encoded inputs (reference models/nerf.py:153-212): no
                               // depth generation / encoding / compositing, 32 points per segment
 template <int NSPLIT, int NCB, int NFX, int MODE>
 __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) {
-    constexpr bool STASH = MODE == NFL_MODE_STASH, EMBED = MODE == NFL_MODE_EMBED;
+    constexpr bool STASH = MODE == NFL_MODE_STASH || MODE == NFL_MODE_STASH2, EMBED = MODE == NFL_MODE_EMBED;
     using C = NflRenderCfg<NSPLIT, NCB, NFX>;
     constexpr int NP = C::NP, NKP = C::NKP, NSLOT = C::NSLOT;
+    constexpr int SMULT = MODE == NFL_MODE_STASH2 ? 2 : 1;                              // records per segment: hi (+ lo)
+    constexpr int LO = MODE == NFL_MODE_STASH2 ? nfl_act_slots(NKP) * 1024 : 0;         // byte offset of the lo record
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // small tables first (so ds_read immediates reach them from one base register), ring last
     float* const bias_lds = reinterpret_cast<float*>(smem);
@@ -771,9 +794,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             // padded segments recompute (and re-store) the last real one: identical bytes, no branch
             // stash k-step image = [sample c][lane half h][8 values]: a sample's 16 features are 32 contiguous
             // bytes, which makes the weight-gradient kernel's transposed LDS reads conflict-free
-            st[cb] = STASH ? K->a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_slots(NKP)) * 1024 + (2 * c + h) * 16
+            st[cb] = STASH ? K->a.d_act_stash + ((size_t)(ray0 * SPR + gg) * nfl_act_rec(NKP, SMULT)) * 1024 + (2 * c + h) * 16
                            : nullptr;
-            mst[cb] = STASH ? K->a.d_act_stash + nfl_msk_offset((size_t)K->a.n_rays * SPR, NKP)
+            mst[cb] = STASH ? K->a.d_act_stash + nfl_msk_offset((size_t)K->a.n_rays * SPR, NKP, SMULT)
                                   + (size_t)(ray0 * SPR + gg) * (NFL_MSK_WORDS * 256) + lane * 16
                             : nullptr;
             s_ray[cb] = ray;
@@ -790,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
             for (int k = 0; k < 3; ++k) nfl_turns(raw[k], th[k], tl[k]);
 #pragma unroll
             for (int ks = 0; ks < NKP; ++ks) {
-                nfl_pe_kstep<NFX, NP>(ks, h, raw, th, tl, pw_lds, P[ks][cb], STASH ? st[cb] + ks * 1024 : nullptr);
+                nfl_pe_kstep<NFX, NP, LO>(ks, h, raw, th, tl, pw_lds, P[ks][cb], STASH ? st[cb] + ks * 1024 : nullptr);
                 __builtin_amdgcn_sched_barrier(0);      // bound the register pressure of the encoder
             }
         }
@@ -802,21 +825,21 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         // accumulator tiles die immediately
         float o_sig[NCB], o_rgb[NCB][3], o_tr[NCB][5];
         NFL_STAMP(0);
-        nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1), mst, nfl_msk_h(1));       // L1
+        nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH, LO>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1), mst, nfl_msk_h(1));       // L1
         NFL_STAMP(1);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2), mst, nfl_msk_h(2));        // L2
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2), mst, nfl_msk_h(2));        // L2
         NFL_STAMP(2);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3), mst, nfl_msk_h(3));        // L3
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3), mst, nfl_msk_h(3));        // L3
         NFL_STAMP(3);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4), mst, nfl_msk_h(4));        // L4
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4), mst, nfl_msk_h(4));        // L4
         NFL_STAMP(4);
-        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5), mst, nfl_msk_h(5));      // L5 (skip)
+        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5), mst, nfl_msk_h(5));      // L5 (skip)
         NFL_STAMP(5);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6), mst, nfl_msk_h(6));        // L6
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6), mst, nfl_msk_h(6));        // L6
         NFL_STAMP(6);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7), mst, nfl_msk_h(7));        // L7
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7), mst, nfl_msk_h(7));        // L7
         NFL_STAMP(7);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8), mst, nfl_msk_h(8));        // L8
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8), mst, nfl_msk_h(8));        // L8
         NFL_STAMP(8);
         {
             f16v hacc[NCB];
@@ -868,9 +891,9 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
 #pragma unroll
                     for (int k = 0; k < 3; ++k) nfl_turns(raw[k], th[k], tl[k]);
                     char* sd = STASH ? st[cb] + nfl_act_d(NKP) * 1024 : nullptr;
-                    nfl_pe_kstep<4, NP>(0, h, raw, th, tl, pw_lds + 16, D[0][cb], sd);
+                    nfl_pe_kstep<4, NP, LO>(0, h, raw, th, tl, pw_lds + 16, D[0][cb], sd);
                     __builtin_amdgcn_sched_barrier(0);
-                    nfl_pe_kstep<4, NP>(1, h, raw, th, tl, pw_lds + 16, D[1][cb], STASH ? sd + 1024 : nullptr);
+                    nfl_pe_kstep<4, NP, LO>(1, h, raw, th, tl, pw_lds + 16, D[1][cb], STASH ? sd + 1024 : nullptr);
                     __builtin_amdgcn_sched_barrier(0);
                     if (K->has_a) {
                         const float* ap = K->a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;
@@ -880,15 +903,15 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                             const f4v v1 = *reinterpret_cast<const f4v*>(ap + 16 * ks + 4);
                             const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                             nfl_split8<NP>(v, D[2 + ks][cb]);
-                            if (STASH) nfl_stash8(v, sd + (2 + ks) * 1024);
+                            if (STASH) nfl_stash8<LO>(v, sd + (2 + ks) * 1024);
                         }
                     }
                 }
                 NFL_STAMP(11);
                 if (K->has_a)
-                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
+                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
                 else
-                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
+                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
             }
             NFL_STAMP(12);
             {
@@ -922,12 +945,12 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                         v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
                     }
                     nfl_split8<NP>(v, T[0][cb]);
-                    if (STASH) nfl_stash8(v, st[cb] + nfl_act_tau(NKP) * 1024);
+                    if (STASH) nfl_stash8<LO>(v, st[cb] + nfl_act_tau(NKP) * 1024);
                 }
-                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH>(ring, bias_lds, rt, h, Y, 0, T, 0, X, 8, st, nfl_act_g(NKP, 1), mst, nfl_msk_g(1));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 2), mst, nfl_msk_g(2));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, X, 0, X, 0, X, 8, st, nfl_act_g(NKP, 3), mst, nfl_msk_g(3));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 4), mst, nfl_msk_g(4));
+                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, T, 0, X, 8, st, nfl_act_g(NKP, 1), mst, nfl_msk_g(1));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 2), mst, nfl_msk_g(2));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, X, 8, st, nfl_act_g(NKP, 3), mst, nfl_msk_g(3));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 4), mst, nfl_msk_g(4));
                 f16v hacc[NCB];
                 nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, X, 0, hacc);
 #pragma unroll
@@ -1217,6 +1240,8 @@ static int nfl_launch_render(const NflPlan* hp, const void* d_plan, const void* 
     if (args->d_embedded) return nfl_launch_render_t<NSPLIT, NCB, NFX, NFL_MODE_EMBED>(hp, d_plan, d_packed, args, stream);
     if (args->d_act_stash) {
         if (NSPLIT != 3) return NFL_EINVAL;        // the training stash is written by the accurate mode only
+        if (args->stash_split)
+            return nfl_launch_render_t<NSPLIT, NCB, NFX, (NSPLIT == 3 ? NFL_MODE_STASH2 : NFL_MODE_RENDER)>(hp, d_plan, d_packed, args, stream);
         return nfl_launch_render_t<NSPLIT, NCB, NFX, (NSPLIT == 3 ? NFL_MODE_STASH : NFL_MODE_RENDER)>(hp, d_plan, d_packed, args, stream);
     }
     return nfl_launch_render_t<NSPLIT, NCB, NFX, NFL_MODE_RENDER>(hp, d_plan, d_packed, args, stream);

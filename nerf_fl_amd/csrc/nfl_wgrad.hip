@@ -72,6 +72,8 @@ struct WgArgs {
     const char* act;     // activation stash
     const char* grd;     // gradient stash
     int n_seg;
+    int act_rec, grd_rec;            // slots per segment record of the two stashes (twice the plan's with split stashes)
+    int bias_on;                     // 0: this launch adds nothing to the bias gradients (third product of a split backward)
     int wg_start[WG_MAX_JOBS + 1];   // workgroups [wg_start[j], wg_start[j+1]) work on job j
     nfl_field_grads g;
     float* scratch;      // (256, 256): rows 0..127 G (delta_dirh (x) h8), rows 128..255 Gt (delta_g1 (x) h8)
@@ -140,7 +142,7 @@ __device__ __forceinline__ void wg_flush(const WgArgs& A, const WgJob& J, f16v (
                 }
             }
         });
-        if (J.do_bias && wi == 0 && layer != WG_SCRATCH && A.g.bias[layer] != nullptr) {
+        if (J.do_bias && A.bias_on && wi == 0 && layer != WG_SCRATCH && A.g.bias[layer] != nullptr) {
             const float tot = bsum[a] + __shfl_xor(bsum[a], 32);
             const int oi = wg_orig(TO.kind, n);
             if (hh == 0 && oi < TO.nvalid) atomicAdd(A.g.bias[layer] + TO.idx0 + oi, tot);
@@ -289,16 +291,16 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     const int pw = P.cost[j];
     const int nitw = (J.n_it + J.n_wi - 1) / J.n_wi;       // in tiles per wave
     if (pw <= 4) {
-        if (nitw <= 1) wg_body_rs<4, 1, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-        else wg_body_rs<4, 2, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        if (nitw <= 1) wg_body_rs<4, 1, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        else wg_body_rs<4, 2, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     } else if (pw <= 5) {
-        wg_body_rs<5, 2, 8>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        wg_body_rs<5, 2, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     } else if (pw <= 6) {          // G of a pass without the transient head: 4 out x 8 in tiles
-        wg_body_rs<6, 4, 7>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        wg_body_rs<6, 4, 7>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     } else {
-        if (nitw <= 5) wg_body_rs<8, 5, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-        else if (nitw <= 6) wg_body_rs<8, 6, 6>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
-        else wg_body_rs<8, 8, 5>(A, J, P.act_slots, P.grd_slots, seg0, seg1, smem);
+        if (nitw <= 5) wg_body_rs<8, 5, 6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        else if (nitw <= 6) wg_body_rs<8, 6, 6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        else wg_body_rs<8, 8, 5>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     }
 }
 
@@ -555,8 +557,8 @@ extern "C" size_t nfl_wgrad_scratch_bytes(void) { return (size_t)NFL_W * NFL_W *
 
 extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash,
                              const char* d_grad_stash, const float* d_gmax, int32_t n_rays, int32_t n_samples,
-                             const nfl_field_params* params, float* d_scratch, const nfl_field_grads* grads,
-                             void* stream) {
+                             int32_t bwd_prec, const nfl_field_params* params, float* d_scratch,
+                             const nfl_field_grads* grads, void* stream) {
     const WgPlan* hp = static_cast<const WgPlan*>(h_wplan);
     if (!hp || hp->magic != (NFL_PLAN_MAGIC ^ 0x57u) || !d_wplan || !d_act_stash || !d_grad_stash || !d_gmax || !grads
         || !params || !d_scratch)
@@ -568,11 +570,16 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     if ((grads->weight[NFL_P_DIR] || grads->weight[NFL_P_FINAL]) && !grads->bias[NFL_P_DIR]) return NFL_EINVAL;
     if (ut && (grads->weight[NFL_P_T0] || grads->weight[NFL_P_FINAL]) && !grads->bias[NFL_P_T0]) return NFL_EINVAL;
     if (n_rays < 0 || n_samples < 1) return NFL_EINVAL;
+    if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
+    const int mult = bwd_prec == NFL_PREC_F16X3 ? 2 : 1;       // split stashes: [hi record | lo record] per segment
     WgArgs A;
     memset(&A, 0, sizeof(A));
     A.plan = static_cast<const WgPlan*>(d_wplan);
     A.act = d_act_stash;
     A.grd = d_grad_stash;
+    A.act_rec = hp->act_slots * mult;
+    A.grd_rec = hp->grd_slots * mult;
+    A.bias_on = 1;
     A.n_seg = n_rays * ((n_samples + 31) / 32);
     A.g = *grads;
     A.scratch = d_scratch;
@@ -628,6 +635,19 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 0, d_gmax);
     if (n_rays == 0) return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
     hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, A);
+    if (mult == 2) {
+        // three-product weight gradient, dW = sum_s (d_hi + d_lo) (x) (h_hi + h_lo) without the lo x lo term: the same
+        // streaming GEMM over the residual records, accumulated into the same fp32 tensors (fp16 x fp16 products are exact
+        // in the fp32 accumulators, so what is left is the 2^-22 lo x lo term and the summation order).  The bias gradients
+        // are sum_s (d_hi + d_lo): the second launch adds its share, the third (h_lo) none.
+        WgArgs B = A;
+        B.grd = d_grad_stash + (size_t)hp->grd_slots * 1024;
+        hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
+        B = A;
+        B.act = d_act_stash + (size_t)hp->act_slots * 1024;
+        B.bias_on = 0;
+        hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
+    }
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 1, d_gmax);
 
     // the composition through xyz_encoding_final (file header); G, db_dir, db_t0 are final (unscaled) by now

@@ -198,7 +198,7 @@ class _PackedField:
         # dgrad stream (transposed weights, fp16, one product); built lazily on the first training forward
         self._slots = None        # (submodule, parameter slot, qualified name) of every parameter: _named()
         self.fold = None          # folded copies of dir_encoding.0 / transient_encoding.0 (weight, bias) for the packer
-        self.bplans = {}          # rays_grad -> dict(h, d, packed, nbytes, key)
+        self.bplans = {}          # (rays_grad, backward precision) -> dict(h, d, packed, nbytes, key)
         self.wplans = {}          # use_transient -> (host blob, device copy) of the wgrad job list
         self.wg_scratch = None    # composition scratch of nfl_mlp_wgrad when the gradients go to a caller-owned GradArena
 
@@ -230,23 +230,25 @@ class _PackedField:
                 out.append((i, params[name + ".weight"], params[name + ".bias"]))
         return out
 
-    def bwd_plan(self, rays_grad=False):
-        """Plan + buffer of the dgrad stream (transposed weights, fp16); packed by ensure_bwd_packed / _pack_streams."""
+    def bwd_plan(self, rays_grad=False, bprec=None):
+        """Plan + buffer of the dgrad stream (transposed weights, fp16 -- hi + lo fragments for the three-product backward);
+        packed by ensure_bwd_packed / _pack_streams."""
         L = _lib.lib()
-        rg = int(bool(rays_grad))
+        bprec = _PREC[_backward] if bprec is None else bprec
+        rg = (int(bool(rays_grad)), bprec)
         if rg not in self.bplans:
             nbytes = L.nfl_plan_bytes(C.byref(self.desc))
             h = C.create_string_buffer(nbytes)
-            _lib.check(L.nfl_bwd_plan_build(C.byref(self.desc), rg, h, nbytes), "nfl_bwd_plan_build")
-            pb = L.nfl_bwd_packed_bytes(C.byref(self.desc), rg)
+            _lib.check(L.nfl_bwd_plan_build(C.byref(self.desc), rg[0], bprec, h, nbytes), "nfl_bwd_plan_build")
+            pb = L.nfl_bwd_packed_bytes(C.byref(self.desc), rg[0], bprec)
             self.bplans[rg] = dict(h=h, d=torch.frombuffer(bytearray(h.raw), dtype=torch.uint8).to(self.device),
                                    packed=torch.empty(pb, dtype=torch.uint8, device=self.device), nbytes=pb, key=None)
         return self.bplans[rg]
 
-    def ensure_bwd_packed(self, rays_grad=False):
+    def ensure_bwd_packed(self, rays_grad=False, bprec=None):
         """dgrad stream for the current parameters (the forward stream must be current: self.key)."""
         L = _lib.lib()
-        bp = self.bwd_plan(rays_grad)
+        bp = self.bwd_plan(rays_grad, bprec)
         if bp["key"] != self.key:
             fp, _keep = self._pack_params()
             _lib.check(L.nfl_pack_field(bp["h"], _ptr(bp["d"]), C.byref(fp), _ptr(bp["packed"]), bp["nbytes"],
@@ -422,7 +424,7 @@ def _n_freqs(emb):
 def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, perturb=0.0, use_disp=False,
               noise=None, noise_std=0.0, a_emb=None, t_emb=None, view_dir=None, sigma_only=False,
               white_back=False, test_extras=False, want_rgb=True, want_z=False, field_raw=False, stash=False,
-              pe_w_xyz=None, pe_w_dir=None, loss=None, loss_slot=0):
+              pe_w_xyz=None, pe_w_dir=None, loss=None, loss_slot=0, bprec=_lib.NFL_PREC_F16):
     R = rays.shape[0]
     dev = rays.device
     new = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -441,7 +443,7 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     if field_raw or stash:
         out["field_raw"] = torch.empty(R * n_samples, 9, dtype=torch.float32, device=dev)
     if stash:
-        nb = _lib.lib().nfl_act_stash_bytes(C.byref(field.desc), R, n_samples)
+        nb = _lib.lib().nfl_act_stash_bytes(C.byref(field.desc), R, n_samples, bprec)
         out["act_stash"] = torch.empty(nb, dtype=torch.uint8, device=dev)
     a = _lib.PassArgs()
     if isinstance(rays, CameraRays):
@@ -466,6 +468,7 @@ def _run_pass(field, rays, n_samples, *, z=None, lin=None, perturb_rand=None, pe
     a.d_depth_transient_only = _ptr(out.get("depth_transient_only"))
     a.d_field_raw = _ptr(out.get("field_raw"))
     a.d_act_stash = _ptr(out.get("act_stash"))
+    a.stash_split = int(stash and bprec == _lib.NFL_PREC_F16X3)      # hi + lo records for the three-product backward
     a.d_pe_w_xyz, a.d_pe_w_dir = _ptr(pe_w_xyz), _ptr(pe_w_dir)
     if loss is not None:        # NerfWLoss fused into the per-ray epilogue (include/nerf_fl_amd.h: d_loss_target)
         out["seed_rgb"] = new(R, 3)
@@ -491,7 +494,7 @@ def _forward(cfg, rays, a_emb, t_emb, train):
                    use_disp=cfg["use_disp"], noise=cfg["noise_c"], noise_std=cfg["noise_std"],
                    view_dir=cfg["view_dir"], sigma_only=test_time, white_back=cfg["white_back"],
                    want_z=I > 0 or train, field_raw=raw, stash=train, pe_w_xyz=cfg["pe_w_xyz"], pe_w_dir=cfg["pe_w_dir"],
-                   loss=cfg["loss"] if train else None, loss_slot=0)
+                   loss=cfg["loss"] if train else None, loss_slot=0, bprec=cfg["bprec"])
     result["weights_coarse"] = oc["weights"]
     result["opacity_coarse"] = oc["opacity"]
     if not test_time:
@@ -514,7 +517,7 @@ def _forward(cfg, rays, a_emb, t_emb, train):
         of = _run_pass(f_f, rays, F, z=z_fine, noise=cfg["noise_f"], noise_std=cfg["noise_std"], a_emb=a_emb,
                        t_emb=t_emb if use_t else None, view_dir=cfg["view_dir"], white_back=cfg["white_back"],
                        test_extras=test_time, field_raw=raw, stash=train, pe_w_xyz=cfg["pe_w_xyz"],
-                       pe_w_dir=cfg["pe_w_dir"], loss=cfg["loss"] if train else None, loss_slot=1)
+                       pe_w_dir=cfg["pe_w_dir"], loss=cfg["loss"] if train else None, loss_slot=1, bprec=cfg["bprec"])
         result["weights_fine"] = of["weights"]
         result["opacity_fine"] = of["opacity"]
         if use_t:
@@ -586,7 +589,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     ca.d_gmax = _ptr(gmax)
     _lib.check(L.nfl_composite_backward(C.byref(ca), _stream()), "nfl_composite_backward")
 
-    grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(field.desc), R, N), dtype=torch.uint8, device=dev)
+    grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(field.desc), R, N, cfg["bprec"]), dtype=torch.uint8, device=dev)
     g_a = g_t = None
     tables = cfg["latent_tables"]
     arena = cfg["arena"]
@@ -611,7 +614,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     if g_rays is not None:
         da.d_g_rays, da.d_rays, da.d_z = _ptr(g_rays), _ptr(rays), _ptr(st["z"])
         da.d_pe_w_xyz, da.d_pe_w_dir = _ptr(cfg["pe_w_xyz"]), _ptr(cfg["pe_w_dir"])
-    bp = field.ensure_bwd_packed(cfg["rays_grad"])
+    bp = field.ensure_bwd_packed(cfg["rays_grad"], cfg["bprec"])
     _lib.check(L.nfl_mlp_dgrad(bp["h"], _ptr(bp["d"]), _ptr(bp["packed"]), C.byref(da), _stream()), "nfl_mlp_dgrad")
 
     plist = field.param_list()
@@ -639,7 +642,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
             views += [gw, gb]
     h_wp, d_wp = field.wgrad_plan(use_t)
     fp, _keep = field._field_params()          # the fp32 weights the forward ran with (read by the composition)
-    _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), _ptr(gmax), R, N, C.byref(fp),
+    _lib.check(L.nfl_mlp_wgrad(h_wp, _ptr(d_wp), _ptr(st["act"]), _ptr(grad_stash), _ptr(gmax), R, N, cfg["bprec"], C.byref(fp),
                                C.c_void_p(scratch.data_ptr()), C.byref(fg), _stream()),
                "nfl_mlp_wgrad")
     return views, g_a, g_t
@@ -663,10 +666,10 @@ class _RenderRaysFn(torch.autograd.Function):
             a_rows = None if a_emb is None else _f32c(a_emb, "a_embedded")
             t_rows = None if t_emb is None else _f32c(t_emb, "t_embedded")
         result, saved = _forward(cfg, rays, a_rows, t_rows, train=True)
-        cfg["f_c"].ensure_bwd_packed(cfg["rays_grad"])
+        cfg["f_c"].ensure_bwd_packed(cfg["rays_grad"], cfg["bprec"])
         cfg["f_c"].wgrad_plan(False)
         if cfg["f_f"] is not None:
-            cfg["f_f"].ensure_bwd_packed(cfg["rays_grad"])
+            cfg["f_f"].ensure_bwd_packed(cfg["rays_grad"], cfg["bprec"])
             cfg["f_f"].wgrad_plan(cfg["use_t"])
         if cfg["loss"] is not None:
             terms = cfg["loss"]["losses"]
@@ -731,7 +734,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                    white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
                    view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
                    use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None, loss=None,
-                   latent_tables=False, ts=None, arena=kwargs.get("grad_arena"))
+                   latent_tables=False, ts=None, arena=kwargs.get("grad_arena"), bprec=_PREC[_backward])
         if kwargs.get("loss_target") is not None:
             # build-defined: NerfWLoss (losses.py:35-50) fused into the per-ray epilogue of the training passes.  The result
             # gains `_nerfw_loss` (scalar, the only output that carries gradient then) and `_nerfw_terms` (4,)

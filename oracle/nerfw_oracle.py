@@ -177,7 +177,12 @@ def barf_weights(n_freqs: int, epoch, epoch_start: int = 4, epoch_end: int = 8) 
 # A3: the field MLP               (reference models/nerf.py:153-212)
 # --------------------------------------------------------------------------
 def _lin(P: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
-    return torch.addmm(P[name + ".bias"], x, P[name + ".weight"].t())
+    return torch.nn.functional.linear(x, P[name + ".weight"], P[name + ".bias"])      # what nn.Linear calls
+
+
+def _lin_relu(P: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
+    # nn.Sequential(nn.Linear, nn.ReLU(True)) (models/nerf.py:124-151): the activation overwrites the layer's output
+    return torch.relu_(_lin(P, name, x))
 
 
 def field_forward(spec: FieldSpec, P: Dict[str, Tensor], enc_xyz: Tensor,
@@ -193,18 +198,18 @@ def field_forward(spec: FieldSpec, P: Dict[str, Tensor], enc_xyz: Tensor,
     for i in range(TRUNK_DEPTH):
         if i == SKIP_AT:
             h = torch.cat([enc_xyz, h], dim=1)       # encoded position goes FIRST
-        h = torch.relu(_lin(P, f"xyz_encoding_{i + 1}.0", h))
+        h = _lin_relu(P, f"xyz_encoding_{i + 1}.0", h)
     out = {"sigma": torch.nn.functional.softplus(_lin(P, "static_sigma.0", h))[:, 0]}
     if sigma_only:
         return out
     feat = _lin(P, "xyz_encoding_final", h)          # no activation
-    d = torch.relu(_lin(P, "dir_encoding.0", torch.cat([feat, dir_a], dim=1)))
+    d = _lin_relu(P, "dir_encoding.0", torch.cat([feat, dir_a], dim=1))
     out["rgb"] = torch.sigmoid(_lin(P, "static_rgb.0", d))
     if tau is None:
         return out
     g = torch.cat([feat, tau], dim=1)
     for j in (0, 2, 4, 6):
-        g = torch.relu(_lin(P, f"transient_encoding.{j}", g))
+        g = _lin_relu(P, f"transient_encoding.{j}", g)
     out["sigma_t"] = torch.nn.functional.softplus(_lin(P, "transient_sigma.0", g))[:, 0]
     out["rgb_t"] = torch.sigmoid(_lin(P, "transient_rgb.0", g))
     out["beta"] = torch.nn.functional.softplus(_lin(P, "transient_beta.0", g))[:, 0]
@@ -328,18 +333,30 @@ def composite(typ: str, z: Tensor, f: Dict[str, Tensor], *, noise: Optional[Tens
 # --------------------------------------------------------------------------
 # render_rays                      (reference models/rendering.py:49-289)
 # --------------------------------------------------------------------------
-def _eval_field(spec, P, xyz, dir_enc, a_emb, t_emb, sigma_only, pe_w_xyz=None):
+POINT_CHUNK = 1024 * 32      # the reference's `chunk` default (rendering.py:58): points per field evaluation
+
+
+def _eval_field(spec, P, xyz, dir_enc, a_emb, t_emb, sigma_only, pe_w_xyz=None, chunk=POINT_CHUNK):
+    """The reference's point-chunk loop (rendering.py:98-139): the (R*N, 3) points are encoded and pushed through the
+    field `chunk` rows at a time, the per-ray side inputs repeated per sample, the chunk outputs concatenated."""
     R, N = xyz.shape[:2]
-    enc = posenc(xyz.reshape(-1, 3), spec.n_emb_xyz, pe_w_xyz)
-    if sigma_only:
-        o = field_forward(spec, P, enc, sigma_only=True)
-    else:
+    pts = xyz.reshape(-1, 3)
+    B = pts.shape[0]
+    dir_a = tau = None
+    if not sigma_only:
         side = [dir_enc]
         if spec.encode_appearance:
             side.append(a_emb)
         dir_a = torch.cat(side, dim=1).repeat_interleave(N, dim=0)
         tau = t_emb.repeat_interleave(N, dim=0) if t_emb is not None else None
-        o = field_forward(spec, P, enc, dir_a, tau)
+    parts = []
+    for i in range(0, max(B, 1), chunk):
+        enc = posenc(pts[i:i + chunk], spec.n_emb_xyz, pe_w_xyz)
+        if sigma_only:
+            parts.append(field_forward(spec, P, enc, sigma_only=True))
+        else:
+            parts.append(field_forward(spec, P, enc, dir_a[i:i + chunk], None if tau is None else tau[i:i + chunk]))
+    o = parts[0] if len(parts) == 1 else {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
     return {k: v.reshape(R, N, *v.shape[1:]) for k, v in o.items()}
 
 
@@ -353,7 +370,9 @@ def render_rays(spec_c: FieldSpec, P_c: Dict[str, Tensor],
                 perturb_rand: Optional[Tensor] = None, noise_coarse: Optional[Tensor] = None,
                 u: Optional[Tensor] = None, noise_fine: Optional[Tensor] = None,
                 return_z: bool = False, pe_w_xyz: Optional[Tensor] = None,
-                pe_w_dir: Optional[Tensor] = None) -> Dict[str, Tensor]:
+                pe_w_dir: Optional[Tensor] = None, z_fine: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """z_fine (R, n_samples + n_importance): use these sorted fine depths instead of sampling them (the depths a
+    reference run used, stored in the fixtures: takes the discontinuous sampler out of a comparison)."""
     R = rays.shape[0]
     o, d = rays[:, 0:3], rays[:, 3:6]
     near, far = rays[:, 6:7], rays[:, 7:8]
@@ -370,8 +389,11 @@ def render_rays(spec_c: FieldSpec, P_c: Dict[str, Tensor],
         mid = 0.5 * (z[:, :-1] + z[:, 1:])
         if perturb == 0:
             u = torch.linspace(0, 1, n_importance).expand(R, n_importance)
-        zs = sample_pdf(mid, res["weights_coarse"][:, 1:-1].detach(), u)
-        z = torch.sort(torch.cat([z, zs], dim=1), dim=1)[0]
+        if z_fine is None:
+            zs = sample_pdf(mid, res["weights_coarse"][:, 1:-1].detach(), u)
+            z = torch.sort(torch.cat([z, zs], dim=1), dim=1)[0]
+        else:
+            z = z_fine
         xyz = o[:, None, :] + d[:, None, :] * z[..., None]
         use_t = bool(output_transient and spec_f.encode_transient)
         ff = _eval_field(spec_f, P_f, xyz, dir_enc, a_emb, t_emb if use_t else None, sigma_only=False,

@@ -14,6 +14,10 @@ import test_psnr_parity_gpu as T
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 kind = sys.argv[2] if len(sys.argv) > 2 else "base"
 opts = dict(a.split("=") for a in sys.argv[3:])
+if "backward" in opts:        # backward=f16x3: the three-product (fp32-class) MLP backward
+    import nerf_fl_amd
+    nerf_fl_amd.set_precision(backward=opts.pop("backward"))
+    print("backward arithmetic:", nerf_fl_amd.rendering.get_backward_precision())
 if "_grad_noise" in opts:
     opts["_grad_noise"] = float(opts["_grad_noise"])
 win = 50

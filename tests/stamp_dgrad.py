@@ -27,7 +27,7 @@ out = rnd._run_pass(f, rays, F, z=z, noise=noise, noise_std=1.0, white_back=True
 L = _lib.lib()
 head = torch.randn(R * F, 9, device=dev) * 1e-3
 gmax = torch.full((1024,), 4e-3, device=dev)
-grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(f.desc), R, F), dtype=torch.uint8, device=dev)
+grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(f.desc), R, F, _lib.NFL_PREC_F16), dtype=torch.uint8, device=dev)
 da = _lib.DgradArgs()
 da.d_head_grads, da.d_act_stash, da.d_grad_stash = rnd._ptr(head), rnd._ptr(out["act_stash"]), rnd._ptr(grad_stash)
 da.n_rays, da.n_samples, da.use_transient, da.d_gmax = R, F, 0, rnd._ptr(gmax)

@@ -111,7 +111,8 @@ def test_capturable_adam_follows_a_loaded_checkpoint():
     a = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
     oa = Adam(a, lr=1e-2)
     run(oa, a, range(2))
-    ckpt_params, ckpt_opt = [p.detach().clone() for p in a], oa.state_dict()
+    import copy
+    ckpt_params, ckpt_opt = [p.detach().clone() for p in a], copy.deepcopy(oa.state_dict())    # state_dict() shares the tensors
     run(oa, a, range(2, 5))                                        # the continuation to reproduce
     b = [torch.nn.Parameter(x.clone().to(dev)) for x in base]
     ob = Adam(b, lr=1e-2, capturable=True)

@@ -72,7 +72,7 @@ def test_bwd_plan_structure(L):
     d = _lib.FieldDesc(10, 4, 1, 48, 1, 16, 0.1, 0)
     n = L.nfl_plan_bytes(C.byref(d))
     buf = C.create_string_buffer(n)
-    assert L.nfl_bwd_plan_build(C.byref(d), 0, buf, n) == 0
+    assert L.nfl_bwd_plan_build(C.byref(d), 0, _lib.NFL_PREC_F16, buf, n) == 0
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
     assert hdr[1] == 1 and hdr[2] == 1 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == 0     # fp16 single-product fragments, dgrad stream, no rays-gradient tiles
     n_rt, n_chunks, total_ks = hdr[12], hdr[15], hdr[18]
@@ -82,14 +82,24 @@ def test_bwd_plan_structure(L):
     assert n_chunks == (2 + 6 + 1) + 2 + 2 + 4 + 28
     assert hdr[16] == 9                                     # first chunk of the non-transient part (n_chunks_sigma re-used)
     assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 17 + 56 * 16
-    assert L.nfl_bwd_packed_bytes(C.byref(d), 0) == total_ks * 1024 + n_rt * 128
+    assert L.nfl_bwd_packed_bytes(C.byref(d), 0, _lib.NFL_PREC_F16) == total_ks * 1024 + n_rt * 128
     # with the gradient w.r.t. the rays: + direction rows (1 tile, 8 ks) + encoded-position rows of layers 5 and 1 (2 x 2 tiles, 16 ks)
-    assert L.nfl_bwd_plan_build(C.byref(d), 1, buf, n) == 0
+    assert L.nfl_bwd_plan_build(C.byref(d), 1, _lib.NFL_PREC_F16, buf, n) == 0
     hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)
     assert hdr2[5] == 1 and hdr2[12] == n_rt + 5 and hdr2[15] == n_chunks + 5 and hdr2[18] == total_ks + 8 + 4 * 16
+    # the three-product (fp32-class) backward: the same tiles as hi + lo fragments (2 KiB per k-step), one tile per chunk
+    assert L.nfl_bwd_plan_build(C.byref(d), 0, _lib.NFL_PREC_F16X3, buf, n) == 0
+    hdr3 = np.frombuffer(buf.raw[:96], dtype=np.int32)
+    assert hdr3[2] == 3 and hdr3[4] == 1 and hdr3[12] == n_rt and hdr3[15] == n_rt and hdr3[18] == total_ks
+    assert hdr3[16] == 17                                   # transient part: 17 tiles = 17 chunks
+    assert L.nfl_bwd_packed_bytes(C.byref(d), 0, _lib.NFL_PREC_F16X3) == total_ks * 2048 + n_rt * 128
+    assert L.nfl_bwd_plan_build(C.byref(d), 0, 7, buf, n) == -1
     # stash sizes: per 32-sample segment 178 / 173 KiB (no slot for xyz_encoding_final's output or its gradient: composed) (+ 4 KiB tail pad), then 84 relu-mask words x 256 B per segment
-    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128) == 8 * 4 * 178 * 1024 + 4096 + 8 * 4 * 84 * 256
-    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100) == (8 * 4 + 1) * 173 * 1024 + 4096
+    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128, _lib.NFL_PREC_F16) == 8 * 4 * 178 * 1024 + 4096 + 8 * 4 * 84 * 256
+    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100, _lib.NFL_PREC_F16) == (8 * 4 + 1) * 173 * 1024 + 4096
+    # split (hi + lo) records for the three-product backward: twice the record, the same mask words
+    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128, _lib.NFL_PREC_F16X3) == 8 * 4 * 2 * 178 * 1024 + 4096 + 8 * 4 * 84 * 256
+    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100, _lib.NFL_PREC_F16X3) == (8 * 4 + 1) * 2 * 173 * 1024 + 4096
 
 
 def test_unsupported_configs_rejected(L):
@@ -132,7 +142,7 @@ def test_auxiliary_entry_points_validate_arguments(L):
     assert L.nfl_field_forward(None, None, None, None, 4, 90, 0, 0, None, None) == -1
     assert L.nfl_posenc(None, 4, 10, None, None, None) == -1
     assert L.nfl_composite_backward(None, None) == -1 and L.nfl_mlp_dgrad(None, None, None, None, None) == -1
-    assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, None, None, None, None) == -1
+    assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, 1, None, None, None, None) == -1
     assert L.nfl_wgrad_scratch_bytes() == 256 * 256 * 4
     assert L.nfl_pack_fields(0, None, None) == 0                                            # nothing to do
     assert L.nfl_pack_fields(1, None, None) == -1 and L.nfl_pack_fields(_lib.NFL_PACK_MAX_JOBS + 1, None, None) == -1

@@ -47,21 +47,45 @@ THRESH = {
 }
 
 
-def _limit(measure, key):
-    default, over = THRESH[measure]
+# The opt-in three-product backward (set_precision(backward="f16x3"): hi + lo weight fragments, activations and gradients,
+# the forward's arithmetic; the reference's fp32 precision class).  Measured over all cases (MI355X, round 3): max <= 7.4e-4,
+# l2 <= 1.2e-3, elem <= 4.8e-3, norm <= 4.6e-5, proj <= 4.5e-4 -- and on the trained-weight fixtures (g17_*), where the
+# loss is smooth in the weights, max <= 1.7e-4 (one head; every other tensor ~1e-6).  What is left on the sharpened random
+# fields is not arithmetic of the backward: the reference's own fp32 autograd differs from the same algorithm in fp64 by
+# 7e-4 .. 1e-2 of max|g| on these fixtures (relu / density-threshold decisions that flip with the forward's last bits:
+# tests/report_grads.py --floor), so 1e-4-class agreement is only defined where the reference is that well conditioned.
+THRESH_X3 = {
+    "max": (1.5e-3, {}),
+    "l2": (2.5e-3, {}),
+    "elem": (1e-2, {}),
+    "norm": (1e-4, {}),
+    "proj": (1e-3, {}),
+}
+THRESH_X3_TRAINED = {"max": (4e-4, {}), "l2": (3e-4, {}), "elem": (2.5e-3, {}), "norm": (8e-5, {}), "proj": (5e-5, {})}
+
+
+def _limit(measure, key, table=None):
+    default, over = (table or THRESH)[measure]
     for sub, v in over.items():
         if sub in key:
             return v
     return default
 
 
-def run_case(name):
-    import gpu_util
+def run_case(name, backward="f16"):
     import nerf_fl_amd
+    nerf_fl_amd.set_precision("f16x3", backward=backward)
+    try:
+        return _run_case(name)
+    finally:
+        nerf_fl_amd.set_precision("f16x3", backward="f16")
+
+
+def _run_case(name):
+    import gpu_util
     from nerf_fl_amd import render_rays
     cfg, a = gu.load(name)
     (spec_c, P_c, spec_f, P_f), kw = gu.oracle_kwargs(cfg, a)
-    nerf_fl_amd.set_precision("f16x3")
     dev = gpu_util.DEV
     barf = cfg.get("barf_epoch") is not None
     models = {"coarse": gpu_util.module_from(spec_c, P_c, barf)}
@@ -153,15 +177,17 @@ def compare(cfg, a, got):
             yield "proj", key, abs(float((g.flatten().double() * pr.double()).sum()) - exp.item()) / a["gradnorm." + key[9:]].item()
 
 
+@pytest.mark.parametrize("backward", ["f16", "f16x3"])
 @pytest.mark.parametrize("name", CASES)
-def test_gradients_vs_reference(name):
-    cfg, a, got, loss = run_case(name)
+def test_gradients_vs_reference(name, backward):
+    cfg, a, got, loss = run_case(name, backward)
     assert abs(loss - a["loss"].item()) <= 1e-4 * max(1.0, abs(a["loss"].item()))
+    table = THRESH if backward == "f16" else (THRESH_X3_TRAINED if name.startswith("g17_") else THRESH_X3)
     bad, seen = {}, {m: 0 for m in THRESH}
     for measure, key, val in compare(cfg, a, got):
         seen[measure] += 1
-        if not val <= _limit(measure, key):
-            bad[(measure, key)] = (val, _limit(measure, key))
+        if not val <= _limit(measure, key, table):
+            bad[(measure, key)] = (val, _limit(measure, key, table))
     assert seen["max"] > 10 and seen["elem"] > 10 and seen["norm"] > 10
     if any(k.startswith("gradproj.") for k in a):
         assert seen["proj"] >= 5

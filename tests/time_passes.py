@@ -19,7 +19,10 @@ m = NeRF("fine")
 m.load_state_dict(orc.make_field_params(orc.FieldSpec("fine"), 12, "sharp"))
 m = m.to(dev)
 f = rnd._field(m, 10, 4, dev)
-bp = f.ensure_bwd_packed(False)
+BWD = sys.argv[sys.argv.index("--backward") + 1] if "--backward" in sys.argv else "f16"      # f16 | f16x3
+nerf_fl_amd.set_precision(backward=BWD)
+BP = rnd._PREC[BWD]
+bp = f.ensure_bwd_packed(False, BP)
 rays = orc.make_rays(R, 100).to(dev)
 z = torch.sort(2 + 4 * torch.rand(R, F, device=dev), dim=1)[0]
 noise = torch.randn(R, F, device=dev)
@@ -43,7 +46,7 @@ print("fwd  (inference)      %.3f ms" % timeit(lambda: rnd._run_pass(f, rays, F,
 if prec == "f16x3":
     out = {}
     def fwd_stash():
-        out.update(rnd._run_pass(f, rays, F, z=z, noise=noise, noise_std=1.0, white_back=True, stash=True))
+        out.update(rnd._run_pass(f, rays, F, z=z, noise=noise, noise_std=1.0, white_back=True, stash=True, bprec=BP))
     print("fwd  (training stash) %.3f ms" % timeit(fwd_stash))
     st = dict(z=z, field_raw=out["field_raw"], act=out["act_stash"], noise=noise, use_t=False, n=F)
     cfg = dict(noise_std=1.0, white_back=True)
@@ -51,7 +54,7 @@ if prec == "f16x3":
     grads = [None, None, torch.randn(R, 3, device=dev) * 1e-3, None]
     L = _lib.lib()
     head = torch.empty(R * F, 9, device=dev)
-    grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(f.desc), R, F), dtype=torch.uint8, device=dev)
+    grad_stash = torch.empty(L.nfl_grad_stash_bytes(C.byref(f.desc), R, F, BP), dtype=torch.uint8, device=dev)
     ca = _lib.CompBwdArgs()
     ca.d_field_raw, ca.d_z, ca.d_noise = rnd._ptr(st["field_raw"]), rnd._ptr(z), rnd._ptr(noise)
     ca.noise_std, ca.n_rays, ca.n_samples, ca.use_transient, ca.white_back = 1.0, R, F, 0, 1
@@ -75,5 +78,5 @@ if prec == "f16x3":
     h_wp, d_wp = f.wgrad_plan(False)
     fpar, _keep = f._field_params()
     scratch = torch.empty(L.nfl_wgrad_scratch_bytes() // 4, device=dev)
-    print("wgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_wgrad(h_wp, rnd._ptr(d_wp), rnd._ptr(st["act"]), rnd._ptr(grad_stash), rnd._ptr(gmax), R, F, C.byref(fpar), rnd._ptr(scratch), C.byref(fg), rnd._stream()), "wg")))
+    print("wgrad                 %.3f ms" % timeit(lambda: _lib.check(L.nfl_mlp_wgrad(h_wp, rnd._ptr(d_wp), rnd._ptr(st["act"]), rnd._ptr(grad_stash), rnd._ptr(gmax), R, F, BP, C.byref(fpar), rnd._ptr(scratch), C.byref(fg), rnd._stream()), "wg")))
     print("act stash %.2f GB, grad stash %.2f GB" % (st["act"].numel() / 1e9, grad_stash.numel() / 1e9))
