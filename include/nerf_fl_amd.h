@@ -52,8 +52,8 @@ enum {
 /* One field (reference class NeRF, models/nerf.py:80-151).  W=256, D=8,
  * skips=[4] are fixed, as in every configuration the reference ships. */
 typedef struct nfl_field_desc {
-    int32_t n_emb_xyz;          /* PosEmbedding freqs for xyz: 10 or 15 (opt.py:25; test_phototourism.ipynb) */
-    int32_t n_emb_dir;          /* must be 4 (opt.py:27)                                                       */
+    int32_t n_emb_xyz;          /* PosEmbedding freqs for xyz: 1..15 (opt.py:25 default 10; test_phototourism.ipynb 15)  */
+    int32_t n_emb_dir;          /* PosEmbedding freqs for dir: 1..4 (opt.py:27 default 4)                                */
     int32_t encode_appearance;  /* NeRF-A head: dir layer sees n_a extra inputs (nerf.py:115,134)             */
     int32_t n_a;                /* 48                                                                         */
     int32_t encode_transient;   /* NeRF-U head (nerf.py:141-151)                                              */
@@ -292,7 +292,8 @@ typedef struct nfl_dgrad_args {
     char*        d_grad_stash;      /* out, nfl_grad_stash_bytes()                         */
     int32_t n_rays, n_samples;
     int32_t use_transient;
-    int32_t reserved;
+    int32_t dir_is_data;            /* with d_g_rays: the forward pass was given a separate d_view_dir, so the direction encoding
+                                       does not depend on the rays (rendering.py:236-238): its gradient is left out of d_g_rays */
     float* d_g_a_emb;               /* (R,n_a)  accumulated into (zero it first) or NULL   */
     float* d_g_t_emb;               /* (R,n_tau) accumulated into (zero it first) or NULL  */
     const int64_t* d_latent_row;    /* (R) or NULL.  When set, d_g_a_emb / d_g_t_emb are the gradients of the latent TABLES

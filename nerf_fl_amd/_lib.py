@@ -97,7 +97,7 @@ class CompBwdArgs(C.Structure):
 class DgradArgs(C.Structure):
     _fields_ = [
         ("d_head_grads", C.c_void_p), ("d_act_stash", C.c_void_p), ("d_grad_stash", C.c_void_p),
-        ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("use_transient", C.c_int32), ("reserved", C.c_int32),
+        ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("use_transient", C.c_int32), ("dir_is_data", C.c_int32),
         ("d_g_a_emb", C.c_void_p), ("d_g_t_emb", C.c_void_p), ("d_latent_row", C.c_void_p),
         ("d_g_rays", C.c_void_p), ("d_rays", C.c_void_p), ("d_z", C.c_void_p),
         ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p), ("d_gmax", C.c_void_p),

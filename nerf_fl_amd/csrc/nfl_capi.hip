@@ -39,7 +39,8 @@ static size_t n_segments(int32_t n_rays, int32_t n_samples) {
 }
 size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples, int32_t bwd_prec) {
     if (!d || n_rays < 0 || n_samples < 1 || (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3)) return 0;
-    const int nkp = (6 * d->n_emb_xyz + 3 + 15) / 16;
+    if (d->n_emb_xyz < 1 || d->n_emb_xyz > NFL_MAX_EMB_XYZ) return 0;
+    const int nkp = nfl_nkp_for(d->n_emb_xyz);
     const int mult = bwd_prec == NFL_PREC_F16X3 ? 2 : 1;
     // records (hi, with a three-product backward + lo) + tail pad for 2-k-step tile reads, then the relu-mask words
     return nfl_msk_offset(n_segments(n_rays, n_samples), nkp, mult) + n_segments(n_rays, n_samples) * NFL_MSK_WORDS * 256;
@@ -84,8 +85,8 @@ int nfl_field_forward(const void* h_plan, const void* d_plan, const void* d_pack
                       float* d_out, void* stream) {
     const NflPlan* hp = static_cast<const NflPlan*>(h_plan);
     if (!hp || hp->magic != NFL_PLAN_MAGIC || hp->is_bwd || !d_plan || !d_packed || !d_x || !d_out) return NFL_EINVAL;
-    const int cx = 6 * hp->n_emb_xyz + 3;
-    const int need = sigma_only ? cx : cx + 27 + hp->n_a + ((output_transient && hp->has_t) ? hp->n_tau : 0);
+    const int cx = 6 * hp->n_emb_xyz + 3, cd = hp->ld[NFL_P_DIR] - NFL_W - hp->n_a;
+    const int need = sigma_only ? cx : cx + cd + hp->n_a + ((output_transient && hp->has_t) ? hp->n_tau : 0);
     if (n_points < 0 || row_stride < need) return NFL_EINVAL;
     if (n_points == 0) return NFL_OK;
     nfl_pass_args a;
@@ -120,8 +121,8 @@ const char* nfl_strerror(int code) {
 }
 
 const char* nfl_render_kernel_name(int prec, int n_emb_xyz) {
-    if (prec == NFL_PREC_F16X3) return n_emb_xyz == 15 ? "nfl_render_kernel<3, 1, 15, 0>" : "nfl_render_kernel<3, 1, 10, 0>";
-    return n_emb_xyz == 15 ? "nfl_render_kernel<1, 1, 15, 0>" : "nfl_render_kernel<1, 1, 10, 0>";
+    if (prec == NFL_PREC_F16X3) return n_emb_xyz > 10 ? "nfl_render_kernel<3, 1, 15, 0>" : "nfl_render_kernel<3, 1, 10, 0>";
+    return n_emb_xyz > 10 ? "nfl_render_kernel<1, 1, 15, 0>" : "nfl_render_kernel<1, 1, 10, 0>";
 }
 
 }  // extern "C"

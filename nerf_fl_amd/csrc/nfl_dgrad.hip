@@ -20,14 +20,24 @@
 // reduced over the samples of the ray with wave shuffles and accumulated with fp32 atomics.
 #include "nfl_render_impl.h"
 
-// Single-product kernel (NP = 1): two 32-sample segments (column blocks) per wave -- a row tile is only 16 MFMAs per
-// column block, so the per-tile fixed costs (barrier, weight DMA, LDS reads of the A fragments) are shared by
-// 64 samples; the register file holds it because the walk needs only TWO 16-k-step operand sets (P, Q below).
-// Three-product kernel (NP = 2: hi + lo weight fragments and hi + lo gradients, W_lo d_hi + W_hi d_lo + W_hi d_hi, the
-// forward's f16x3 arithmetic; opt-in, NFL_PREC_F16X3 backward): the operand sets are twice as large, so one segment
-// per wave, and a chunk of the stream is one row tile (two would not fit a ring slot).
+// Both kernels stream hi + lo fp16 fragments of the transposed weights (2 KiB per k-step, one row tile per ring chunk):
+// the chain delta_{l-1} = W_l^T delta_l must see the WEIGHTS to fp32 class.  W_hi alone is the same wrong matrix for every
+// sample of a step and nearly the same from step to step -- a fixed-pattern perturbation of the backward operator that Adam
+// integrates into a systematic offset of the training curve (measured: profiles/r03_psnr_backward_attribution.txt), while
+// the roundings of the gradients themselves are fresh per sample and average out.
+//   NP = 1 (default backward, NFL_PREC_F16): gradients as single fp16 images, two products W_hi d_hi + W_lo d_hi; two
+//     32-sample segments (column blocks) per wave, so the per-tile fixed costs (barrier, weight DMA, LDS reads of the A
+//     fragments) are shared by 64 samples; the register file holds it because the walk needs only TWO 16-k-step operand
+//     sets (P, Q below).
+//   NP = 2 (opt-in, NFL_PREC_F16X3): gradients split hi + lo as well, three products (the forward's f16x3 arithmetic),
+//     split gradient stash; the operand sets are twice as large, so one segment per wave.
 #define DG_NCB(NP) ((NP) == 1 ? 2 : 1)
-#define DG_TPC(NP) ((NP) == 1 ? 2 : 1)
+#define DG_TPC(NP) 1
+#ifdef NFL_DIAG_X3_PRODS
+#define DG_PRODS(NP) ((NP) == 1 ? 5 : NFL_DIAG_X3_PRODS)
+#else
+#define DG_PRODS(NP) ((NP) == 1 ? 5 : 3)      // nfl_tile_p: bit 2 = hi + lo weight fragments under single-image operands
+#endif
 
 struct DgradArgs {
     const NflPlan* plan;
@@ -37,6 +47,7 @@ struct DgradArgs {
     int has_a, has_t, use_t;
     int spr, rays_per_wg, nkp, n_seg_total;
     int rays_tiles;           // the stream carries the encoded-position / direction rows (gradient w.r.t. rays)
+    int nfx_rt, ndir_rt;      // the field's frequency counts (<= the instantiation's; nfl_plan.h, "Encoder widths")
 };
 
 struct DgradArgs;
@@ -51,8 +62,8 @@ template <int NFX, int NP_>
 struct NflDgradCfg {
     static constexpr int NP = NP_, NCB = DG_NCB(NP_), TPC = DG_TPC(NP_);
     static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
-    static constexpr int KSB = 1024 * NP;
-    static constexpr int MAXKS = TPC * 17;               // row tiles per chunk (NP 1: one barrier per pair of tiles)
+    static constexpr int KSB = 2048;                     // hi + lo weight fragments in both kernels
+    static constexpr int MAXKS = TPC * 17;               // one row tile per chunk
     static constexpr int WBYTES = MAXKS * KSB;
     static constexpr int AUXB = 4 * NCB * 1024;
     static constexpr int SLOT = WBYTES + AUXB;
@@ -302,11 +313,11 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         }
         if constexpr (i > 0) {
             DgEpi<MASK, NOUT, NCB, NP> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
-            nfl_tile<NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
+            nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
             ring.note(2 * NCB * NP);     // the epilogue's stash stores, issued at the tile's last k-step
         } else {
             NflNoEpi epi;
-            nfl_tile<NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
+            nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
         }
         // pieces the chunk's k-loops did not get to (piece P0 + k is issued at k-step k of its tile)
         if constexpr (TPC == 1) ring.template pieces<NK, Ring::MAXP>();
@@ -329,7 +340,7 @@ NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, f
         return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile<NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -356,7 +367,7 @@ NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, int h
         return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile<NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -414,8 +425,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         chk_lds[i] = A.plan->chunk_off[i];
         aux_lds[i] = A.plan->chunk_aux[i];
     }
-    if (tid < 16) pw_lds[tid] = (a.d_pe_w_xyz && tid < NFX) ? a.d_pe_w_xyz[tid] : 1.f;
-    else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid < 20) ? a.d_pe_w_dir[tid - 16] : 1.f;
+    if (tid < 16) pw_lds[tid] = (a.d_pe_w_xyz && tid < A.nfx_rt) ? a.d_pe_w_xyz[tid] : 1.f;
+    else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid - 16 < A.ndir_rt) ? a.d_pe_w_dir[tid - 16] : 1.f;
     __syncthreads();
 
     // loss scale of this pass (uniform; see nfl_plan.h)
@@ -578,7 +589,8 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const float gxk = gx[cb][k] + __shfl_xor(gx[cb][k], 32);
-                        const float gdk = gd[cb][k] + __shfl_xor(gd[cb][k], 32);
+                        // with a separate view_dir the direction encoding is data (rendering.py:236-238): no share for rays_d
+                        const float gdk = K->a.dir_is_data ? 0.f : gd[cb][k] + __shfl_xor(gd[cb][k], 32);
                         const float so = nfl_sum32(gxk) * inv_scale;
                         const float sd = nfl_sum32(gxk * zs[cb] + gdk) * inv_scale;
                         if (lane == 0 && seg_ok[cb]) {
@@ -621,6 +633,8 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     A.nkp = hp->nkp;
     A.n_seg_total = args->n_rays * A.spr;
     A.rays_tiles = hp->reserved_flags & 1;
+    A.nfx_rt = hp->n_emb_xyz;
+    A.ndir_rt = (hp->reserved_flags >> 8) & 0xff;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int rpw = (args->n_rays + ncu - 1) / ncu;
@@ -648,12 +662,13 @@ extern "C" int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, con
     if (args->n_rays < 0 || args->n_samples < 1) return NFL_EINVAL;
     if (args->n_rays == 0) return NFL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hp->nsplit == 3) {          // three-product (fp32-class) backward: hi + lo fragments, split stashes
-        if (hp->n_emb_xyz == 10) return launch_dgrad<10, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
-        if (hp->n_emb_xyz == 15) return launch_dgrad<15, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->nsplit != 3) return NFL_EINVAL;      // both kernels read hi + lo weight fragments
+    if (hp->prec == NFL_PREC_F16X3) {          // three-product (fp32-class) backward: split gradients and stashes
+        if (hp->n_emb_xyz <= 10) return launch_dgrad<10, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+        if (hp->n_emb_xyz <= 15) return launch_dgrad<15, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
         return NFL_EINVAL;
     }
-    if (hp->n_emb_xyz == 10) return launch_dgrad<10, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
-    if (hp->n_emb_xyz == 15) return launch_dgrad<15, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->n_emb_xyz <= 10) return launch_dgrad<10, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->n_emb_xyz <= 15) return launch_dgrad<15, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
     return NFL_EINVAL;
 }

@@ -84,8 +84,8 @@ static void common_init(const nfl_field_desc* d, int prec, NflPlan* p) {
     p->nsplit = prec == NFL_PREC_F16X3 ? 3 : 1;
     p->ks_bytes = prec == NFL_PREC_F16X3 ? 2048 : 1024;
     p->n_emb_xyz = d->n_emb_xyz;
-    const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
-    p->nkp = (cx + 15) / 16;
+    const int cx = 6 * d->n_emb_xyz + 3, cd = 6 * d->n_emb_dir + 3;
+    p->nkp = nfl_nkp_for(d->n_emb_xyz);
     p->has_a = d->encode_appearance ? 1 : 0;
     p->has_t = d->encode_transient ? 1 : 0;
     p->n_a = p->has_a ? d->n_a : 0;
@@ -105,8 +105,8 @@ static void common_init(const nfl_field_desc* d, int prec, NflPlan* p) {
 
 static int check_desc(const nfl_field_desc* d) {
     if (!d) return NFL_EINVAL;
-    if (d->n_emb_xyz != 10 && d->n_emb_xyz != 15) return NFL_EINVAL;
-    if (d->n_emb_dir != 4) return NFL_EINVAL;
+    if (d->n_emb_xyz < 1 || d->n_emb_xyz > NFL_MAX_EMB_XYZ) return NFL_EINVAL;
+    if (d->n_emb_dir < 1 || d->n_emb_dir > NFL_MAX_EMB_DIR) return NFL_EINVAL;
     if (d->encode_appearance && d->n_a != 48) return NFL_EINVAL;
     if (d->encode_transient && d->n_tau != 16) return NFL_EINVAL;
     return NFL_OK;
@@ -118,14 +118,15 @@ static int check_desc(const nfl_field_desc* d) {
 extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, int bwd_prec, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
     if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
-    // fp16 fragments, gradients loss-scaled (nfl_loss_scale_from_bits): one product, or hi + lo fragments for the
-    // three-product (fp32-class) backward.  The single-product kernel walks its tile groups two tiles per chunk (one
-    // barrier per pair); with hi + lo fragments a pair would not fit a ring slot, so that stream has one tile per chunk.
-    common_init(d, bwd_prec, p);
-    const bool pair = bwd_prec == NFL_PREC_F16;
+    // hi + lo fp16 fragments of the transposed weights for BOTH backward arithmetics (the chain needs the weights to fp32
+    // class: nfl_dgrad.hip); gradients loss-scaled (nfl_loss_scale_from_bits).  One row tile per chunk (two 2 KiB-per-
+    // k-step tiles would not fit a ring slot).  `prec` records which kernel reads the stream.
+    common_init(d, NFL_PREC_F16X3, p);
+    p->prec = bwd_prec;
+    const bool pair = false;
     p->elem = 0;
     p->is_bwd = 1;
-    const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
+    const int cx = 6 * d->n_emb_xyz + 3, cd = 6 * d->n_emb_dir + 3;
     const int W = NFL_W, H = NFL_W / 2, nkp = p->nkp;
     Builder b{p};
     if (p->has_t) {
@@ -158,21 +159,21 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, int bwd
             if (p->has_t) Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_T0);
             Builder::seg(r, 1, NFL_SEG_NAT, 0, 1, NFL_P_SIGMA);
         }, pair && (t & 1));
-    const int npe = (cx + 31) / 32;         // 32-row tiles covering the encoded position
+    const int npe = (nkp + 1) / 2;          // 32-row tiles covering the encoded position AS THE KERNEL WALKS IT (its instantiation's width; rows beyond cx are zero)
     for (int l = 8; l >= 2; --l) {          // layer l (1-based) transposed -> gradient of h_{l-1}
         for (int t = 0; t < 8; ++t)
             b.ttile((l == 5 ? cx : 0) + 32 * t, 32, nfl_msk_h(l - 1) + t,
                     [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + l - 1); }, pair && (t & 1));
         if (l == 5 && rays_grad)            // skip connection: rows that multiply the encoded position
             for (int t = 0; t < npe; ++t)
-                b.ttile(32 * t, cx - 32 * t < 32 ? cx - 32 * t : 32, -1,
+                b.ttile(32 * t, cx - 32 * t < 32 ? (cx - 32 * t > 0 ? cx - 32 * t : 0) : 32, -1,
                         [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1 + 4); });
     }
     if (rays_grad)                          // layer 1 transposed -> gradient of the encoded position
         for (int t = 0; t < npe; ++t)
-            b.ttile(32 * t, cx - 32 * t < 32 ? cx - 32 * t : 32, -1,
+            b.ttile(32 * t, cx - 32 * t < 32 ? (cx - 32 * t > 0 ? cx - 32 * t : 0) : 32, -1,
                     [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1); });
-    p->reserved_flags = rays_grad ? 1 : 0;
+    p->reserved_flags = (rays_grad ? 1 : 0) | (d->n_emb_dir << 8);
     p->n_rt_sigma = p->n_rt_static = p->n_rt;
     p->n_chunks_static = p->n_chunks;
     p->n_chunks_sigma = first_static_chunk;          // (field re-used by the dgrad stream)
@@ -189,7 +190,7 @@ extern "C" int nfl_plan_fill(const nfl_field_desc* d, int prec, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
     if (prec != NFL_PREC_F16X3 && prec != NFL_PREC_F16) return NFL_EINVAL;
     common_init(d, prec, p);
-    const int cx = 6 * d->n_emb_xyz + 3, cd = 27;
+    const int cx = 6 * d->n_emb_xyz + 3, cd = 6 * d->n_emb_dir + 3;
     const int W = NFL_W, H = NFL_W / 2, nkp = p->nkp;
 
     Builder b{p};

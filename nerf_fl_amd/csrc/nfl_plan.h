@@ -31,6 +31,11 @@
 #include <stdint.h>
 
 #define NFL_PLAN_MAGIC 0x4e464c31u /* "NFL1" */
+#if defined(__HIPCC__)
+#define NFL_HD_EARLY __host__ __device__ inline constexpr
+#else
+#define NFL_HD_EARLY inline constexpr
+#endif
 #define NFL_W 256
 #define NFL_MAX_RT 112
 #define NFL_MAX_CHUNKS 104
@@ -38,6 +43,16 @@
 // k-slot -> input-column maps
 #define NFL_SEG_ACT 0   // produced by a previous row tile: k-slot (ks,h,j) <-> column 32*(ks>>1) + 16*(ks&1) + 8*(j>>2) + 4*h + (j&3)
 #define NFL_SEG_NAT 1   // built directly by the lanes:      k-slot (ks,h,j) <-> column 16*ks + 8*h + j
+
+// Encoder widths (reference opt.py:25-28: --N_emb_xyz / --N_emb_dir are free integers).  The kernels are instantiated
+// for two position-encoding k-step counts: 4 (up to 10 frequencies, 63 features) and 6 (up to 15, 93).  A narrower
+// encoder runs in the next wider instantiation: the kernel still evaluates all its sin / cos features, but the packed
+// weights of the columns beyond 6 N + 3 are zero (the packer pads), so they contribute nothing -- forward, dgrad and wgrad
+// alike (their tile descriptors carry the true column counts).  The direction encoder has two k-steps: N_emb_dir <= 4.
+#define NFL_MAX_EMB_XYZ 15
+#define NFL_MAX_EMB_DIR 4
+NFL_HD_EARLY int nfl_kernel_nfx(int n_emb_xyz) { return n_emb_xyz <= 10 ? 10 : 15; }       // instantiation that runs it
+NFL_HD_EARLY int nfl_nkp_for(int n_emb_xyz) { return (6 * nfl_kernel_nfx(n_emb_xyz) + 3 + 15) / 16; }
 
 struct NflBlk {      // rows [src_row0, src_row0+nrows) of layer `layer` land on tile rows dst_row..
     int16_t layer, nrows, src_row0, dst_row;
@@ -63,8 +78,8 @@ struct NflPlan {
     int32_t prec, nsplit;         // nsplit = 1 or 3 products; frags carry (nsplit==3 ? hi+lo : hi)
     int32_t elem;                 // 0: fp16 fragments (both streams now), 1: bf16 fragments
     int32_t is_bwd;               // 1: this is the dgrad (transposed) stream
-    int32_t reserved_flags;       // dgrad stream: bit 0 = carries the tiles for the gradient w.r.t. the rays
-    int32_t n_emb_xyz, nkp;       // nkp = ceil((6*n_emb_xyz+3)/16)
+    int32_t reserved_flags;       // dgrad stream: bit 0 = carries the tiles for the gradient w.r.t. the rays; bits 8..15: n_emb_dir
+    int32_t n_emb_xyz, nkp;       // nkp = k-steps of the encoded position in the kernel instantiation that runs this field (nfl_nkp_for)
     int32_t has_a, has_t, n_a, n_tau;
     int32_t n_rt, n_rt_sigma, n_rt_static;
     int32_t n_chunks, n_chunks_sigma, n_chunks_static;   // dgrad stream: n_chunks_sigma = first chunk after the transient head's

@@ -34,7 +34,9 @@
 #include <type_traits>
 
 #include "../../include/nerf_fl_amd.h"
+#include "nfl_diag.h"
 #include "nfl_plan.h"
+#include "nfl_prods.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
@@ -88,6 +90,8 @@ struct RenderArgs {
     int rays_per_wg;
     float beta_min;
     int n_points, emb_stride;   // NFL_MODE_EMBED: rows / row stride (floats) of a.d_embedded
+    int nfx_rt, ndir_rt;        // the field's frequency counts (<= the instantiation's: nfl_plan.h, "Encoder widths")
+    int cx, cd;                 // 6 nfx_rt + 3, 6 ndir_rt + 3: widths of the encoded position / direction
     int gen_rays;               // rays come from `cam` (nfl_pass_args::h_cam), not from a.d_rays
     nfl_camera cam;
 };
@@ -367,9 +371,9 @@ NFL_DEV nfl_u4 nfl_lds_read128(unsigned addr) {
     return r;
 }
 // wait until at most N LDS operations are outstanding; the operands ride through so that their users stay below
-template <int N, int NP>
-NFL_DEV void nfl_lds_wait(nfl_u4 (&w)[NP]) {
-    if constexpr (NP == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
+template <int N, int NREAD, int NWP>
+NFL_DEV void nfl_lds_wait(nfl_u4 (&w)[NWP]) {
+    if constexpr (NREAD == 2) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(w[0]), "+v"(w[1]) : "n"(N));
     else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(w[0]) : "n"(N));
 }
 
@@ -379,17 +383,27 @@ NFL_DEV void nfl_lds_wait(nfl_u4 (&w)[NP]) {
 #ifndef NFL_DEPTH_X3
 #define NFL_DEPTH_X3 2
 #endif
-template <int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring, int DEPTH = (NP == 1 ? 4 : NFL_DEPTH_X3)>
-NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& getb, Epi&& epi, Ring& ring) {
-    constexpr int KSB = 1024 * NP;
+// PRODS (three-product mode only): which of the two correction products a layer issues besides w_hi x_hi --
+// bit 0: w_lo x_hi (the weights' fp16 residuals; without it the layer's weights are fp16-rounded and their lo fragments
+// are not even read from LDS), bit 1: w_hi x_lo (the activations' residuals).  3 = the full f16x3 product.  The per-layer
+// plan is NFL_PRODS (nfl_prods.h), chosen by measurement against the parity bar (tests/report_parity.py).
+// bit 2 (NP == 1 only): the stream carries hi + lo WEIGHT fragments although the B operands are single fp16 images -- the
+// default dgrad (nfl_dgrad.hip): W_hi d_hi + W_lo d_hi, the weights to fp32 class, the gradients fp16.
+template <int PRODS, int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring,
+          int DEPTH = ((NP == 1 && (PRODS & 4) == 0) ? 4 : NFL_DEPTH_X3)>
+NFL_DEV void nfl_tile_p(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& getb, Epi&& epi, Ring& ring) {
+    constexpr int NWP = (NP == 2 || (PRODS & 4) != 0) ? 2 : 1;          // weight fragments per k-step: hi (+ lo)
+    constexpr int KSB = 1024 * NWP;
     constexpr int NW = DEPTH + 1;
+    constexpr bool W_LO = NWP == 2 && (PRODS & 1) != 0, X_LO = NP == 2 && (PRODS & 2) != 0;
+    constexpr int NREAD = W_LO ? 2 : 1;     // LDS reads per k-step
     (void)frag0;                          // == P0 (kept in the signature for the callers' readability)
-    nfl_u4 w[NW][NP];
+    nfl_u4 w[NW][NWP];
     const unsigned wa = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)wl;
     auto load = [&](auto K) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value;
         w[k % NW][0] = nfl_lds_read128<(P0 + k) * KSB>(wa);
-        if constexpr (NP == 2) w[k % NW][NP - 1] = nfl_lds_read128<(P0 + k) * KSB + 1024>(wa);
+        if constexpr (W_LO) w[k % NW][NWP - 1] = nfl_lds_read128<(P0 + k) * KSB + 1024>(wa);
     };
     nfl_static_for<0, (DEPTH < NK ? DEPTH : NK)>([&](auto K) __attribute__((always_inline)) { load(K); });
     epi.early();                         // VALU work that hides the latency of the first LDS reads
@@ -398,28 +412,38 @@ NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& 
         constexpr int k = decltype(K)::value;
         // k-step k has landed; the reads of k+1 .. k+DEPTH-1 (already issued) may still be in flight
         constexpr int younger = (NK - 1 - k) < (DEPTH - 1) ? (NK - 1 - k) : (DEPTH - 1);
-        nfl_lds_wait<younger * NP, NP>(w[k % NW]);
+        nfl_lds_wait<younger * NREAD, NREAD>(w[k % NW]);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            if (NP == 2) {
-                acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][NP - 1]), getb(K, cb, 0), acc[cb]);
+            // fillers of the k-step (the LDS reads of k + DEPTH, one DMA piece) ride behind its first two MFMAs
+            if constexpr (W_LO) {
+                acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][NWP - 1]), getb(K, cb, 0), acc[cb]);
                 if (cb == 0) {
                     if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (X_LO) {
                 acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, NP - 1), acc[cb]);
-                if (cb == 0) ring.template piece<P0 + k>();
+                if (cb == 0) {
+                    if constexpr (!W_LO && k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
+                    ring.template piece<P0 + k>();
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             acc[cb] = nfl_mfma(__builtin_bit_cast(V8, w[k % NW][0]), getb(K, cb, 0), acc[cb]);
-            if (NP == 1 && cb == 0) {
-                if constexpr (k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
-                ring.template piece<P0 + k>();
+            if (cb == 0) {
+                if constexpr (!W_LO && !X_LO && k + DEPTH < NK) load(std::integral_constant<int, k + DEPTH>{});
+                if constexpr (!X_LO) ring.template piece<P0 + k>();
             }
             if (cb == NCB - 1) epi.template step<k, NK>();
             __builtin_amdgcn_sched_barrier(0);
         }
     });
+}
+template <int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring>
+NFL_DEV void nfl_tile(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& getb, Epi&& epi, Ring& ring) {
+    nfl_tile_p<3, NP, NCB, NK, P0, V8>(acc, wl, frag0, getb, epi, ring);
 }
 
 // max over the NFL_GMAX_SLOTS words the compositing backward left (bit patterns of non-negative floats order
@@ -531,7 +555,7 @@ struct NflActEpi {
 
 // A dense layer of NRT row tiles reading inA[ksA0..+NKA) then inB[ksB0..+NKB), TPC tiles per
 // ring chunk.  The epilogue of tile i-1 rides in the MFMA shadows of tile i.
-template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool STASH, int LO = 0, int NINA, int NINB, int NOUT, class Ring>
+template <int NP, int NCB, int NKA, int NKB, bool RELU, int NRT, int TPC, bool STASH, int LO = 0, int PRODS = 3, int NINA, int NINB, int NOUT, class Ring>
 NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
                        const h8 (&inA)[NINA][NCB][NP], int ksA0,
                        const h8 (&inB)[NINB][NCB][NP], int ksB0,
@@ -556,10 +580,10 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
         nfl_bias_init<NP, NCB>(acc[i & 1], bias_lds + (rt + i) * 32, h);
         if constexpr (i > 0) {
             NflActEpi<NP, NCB, RELU, STASH, NOUT, (i - 1) & 3, LO> epi{acc[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), stash, slot0 + 2 * (i - 1), mstash, mw0 + i - 1, mq, ring.ovf};
-            nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
+            nfl_tile_p<PRODS, NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
         } else {
             NflNoEpi epi;
-            nfl_tile<NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
+            nfl_tile_p<PRODS, NP, NCB, NK, frag0, h8>(acc[i & 1], wl, frag0, getb, epi, ring);
         }
         // pieces the k-loop of this chunk did not get to
         if (i % TPC == TPC - 1 || i == NRT - 1) ring.template pieces<((i % TPC) + 1) * NK, Ring::MAXP>();
@@ -570,7 +594,7 @@ NFL_DEV void nfl_dense(Ring& ring, const float* bias_lds, int& rt, int h,
 }
 
 // a single head tile (own chunk); the caller interprets the accumulator rows
-template <int NP, int NCB, int NK, int NIN, class Ring>
+template <int NP, int NCB, int NK, int PRODS = 3, int NIN, class Ring>
 NFL_DEV void nfl_head(Ring& ring, const float* bias_lds, int& rt, int h,
                       const h8 (&in)[NIN][NCB][NP], int ks0, f16v (&acc)[NCB]) {
     const char* wl = ring.consume();
@@ -579,7 +603,7 @@ NFL_DEV void nfl_head(Ring& ring, const float* bias_lds, int& rt, int h,
         return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile<NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile_p<PRODS, NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
     rt += 1;
 }
@@ -713,8 +737,8 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         const float* bg = reinterpret_cast<const float*>(A.packed + A.bias_off);
         for (int i = tid; i < A.n_rt * 32; i += 256) bias_lds[i] = bg[i];
         for (int i = tid; i <= A.n_chunks; i += 256) chk_lds[i] = A.plan->chunk_off[i];
-        if (tid < 16) pw_lds[tid] = (a.d_pe_w_xyz && tid < NFX) ? a.d_pe_w_xyz[tid] : 1.f;
-        else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid < 20) ? a.d_pe_w_dir[tid - 16] : 1.f;
+        if (tid < 16) pw_lds[tid] = (a.d_pe_w_xyz && tid < A.nfx_rt) ? a.d_pe_w_xyz[tid] : 1.f;
+        else if (tid < 32) pw_lds[tid] = (a.d_pe_w_dir && tid - 16 < A.ndir_rt) ? a.d_pe_w_dir[tid - 16] : 1.f;
         else if (tid < 36) loss_lds[tid - 32] = 0.f;
     }
     __syncthreads();
@@ -772,7 +796,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int f = 16 * ks + 8 * h + j;
-                        v[j] = f < 6 * NFX + 3 ? xr[f] : 0.f;
+                        v[j] = f < K->cx ? xr[f] : 0.f;
                     }
                     nfl_split8<NP>(v, P[ks][cb]);
                 }
@@ -825,25 +849,25 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
         // accumulator tiles die immediately
         float o_sig[NCB], o_rgb[NCB][3], o_tr[NCB][5];
         NFL_STAMP(0);
-        nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH, LO>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1), mst, nfl_msk_h(1));       // L1
+        nfl_dense<NP, NCB, NKP, 0, true, 8, 2, STASH, LO, NFL_PRODS[NFL_P_IDX_L1]>(ring, bias_lds, rt, h, P, 0, P, 0, X, 0, st, nfl_act_h(NKP, 1), mst, nfl_msk_h(1));       // L1
         NFL_STAMP(1);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2), mst, nfl_msk_h(2));        // L2
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_L2]>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 2), mst, nfl_msk_h(2));        // L2
         NFL_STAMP(2);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3), mst, nfl_msk_h(3));        // L3
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_L3]>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 3), mst, nfl_msk_h(3));        // L3
         NFL_STAMP(3);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4), mst, nfl_msk_h(4));        // L4
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_L4]>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 4), mst, nfl_msk_h(4));        // L4
         NFL_STAMP(4);
-        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5), mst, nfl_msk_h(5));      // L5 (skip)
+        nfl_dense<NP, NCB, NKP, 16, true, 8, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_L5]>(ring, bias_lds, rt, h, P, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 5), mst, nfl_msk_h(5));      // L5 (skip)
         NFL_STAMP(5);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6), mst, nfl_msk_h(6));        // L6
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_L6]>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 6), mst, nfl_msk_h(6));        // L6
         NFL_STAMP(6);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7), mst, nfl_msk_h(7));        // L7
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_L7]>(ring, bias_lds, rt, h, Y, 0, Y, 0, X, 0, st, nfl_act_h(NKP, 7), mst, nfl_msk_h(7));        // L7
         NFL_STAMP(7);
-        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8), mst, nfl_msk_h(8));        // L8
+        nfl_dense<NP, NCB, 16, 0, true, 8, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_L8]>(ring, bias_lds, rt, h, X, 0, X, 0, Y, 0, st, nfl_act_h(NKP, 8), mst, nfl_msk_h(8));        // L8
         NFL_STAMP(8);
         {
             f16v hacc[NCB];
-            nfl_head<NP, NCB, 16>(ring, bias_lds, rt, h, Y, 0, hacc);                          // sigma
+            nfl_head<NP, NCB, 16, NFL_PRODS[NFL_P_IDX_SIG]>(ring, bias_lds, rt, h, Y, 0, hacc);   // sigma
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) o_sig[cb] = hacc[cb][0];
         }
@@ -860,7 +884,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     if constexpr (EMBED) {
                         const int b = s_ray[cb] * 32 + s_idx[cb];
                         const float* xr = K->a.d_embedded + (size_t)(b < K->n_points ? b : K->n_points - 1) * K->emb_stride
-                                          + 6 * NFX + 3;
+                                          + K->cx;
 #pragma unroll
                         for (int ks = 0; ks < 5; ++ks) {
                             if (ks >= 2 && !K->has_a) break;
@@ -868,7 +892,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const int f = 16 * (ks < 2 ? ks : ks - 2) + 8 * h + j;
-                                v[j] = ks < 2 ? (f < 27 ? xr[f] : 0.f) : xr[27 + f];
+                                v[j] = ks < 2 ? (f < K->cd ? xr[f] : 0.f) : xr[K->cd + f];
                             }
                             nfl_split8<NP>(v, D[ks][cb]);
                         }
@@ -909,14 +933,14 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 }
                 NFL_STAMP(11);
                 if (K->has_a)
-                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
+                    nfl_dense<NP, NCB, 16, 5, true, 4, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_DIR]>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
                 else
-                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
+                    nfl_dense<NP, NCB, 16, 2, true, 4, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_DIR]>(ring, bias_lds, rt, h, Y, 0, D, 0, X, 0, st, nfl_act_dirh(NKP), mst, nfl_msk_dirh());
             }
             NFL_STAMP(12);
             {
                 f16v hacc[NCB];
-                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, X, 0, hacc);
+                nfl_head<NP, NCB, 8, NFL_PRODS[NFL_P_IDX_RGB]>(ring, bias_lds, rt, h, X, 0, hacc);
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
                     o_rgb[cb][0] = hacc[cb][0];
@@ -932,7 +956,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 for (int cb = 0; cb < NCB; ++cb) {
                     const int tb = s_ray[cb] * 32 + s_idx[cb];
                     const float* tp = EMBED ? K->a.d_embedded + (size_t)(tb < K->n_points ? tb : K->n_points - 1) * K->emb_stride
-                                                  + 6 * NFX + 3 + 27 + (K->has_a ? 48 : 0) + 8 * h
+                                                  + K->cx + K->cd + (K->has_a ? 48 : 0) + 8 * h
                                             : K->a.d_t_emb + (size_t)s_ray[cb] * 16 + 8 * h;
                     float v[8];
                     if constexpr (EMBED) {          // rows of the encoded matrix are not 16-byte aligned
@@ -947,12 +971,12 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     nfl_split8<NP>(v, T[0][cb]);
                     if (STASH) nfl_stash8<LO>(v, st[cb] + nfl_act_tau(NKP) * 1024);
                 }
-                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH, LO>(ring, bias_lds, rt, h, Y, 0, T, 0, X, 8, st, nfl_act_g(NKP, 1), mst, nfl_msk_g(1));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 2), mst, nfl_msk_g(2));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO>(ring, bias_lds, rt, h, X, 0, X, 0, X, 8, st, nfl_act_g(NKP, 3), mst, nfl_msk_g(3));
-                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 4), mst, nfl_msk_g(4));
+                nfl_dense<NP, NCB, 16, 1, true, 4, 1, STASH, LO, NFL_PRODS[NFL_P_IDX_T1]>(ring, bias_lds, rt, h, Y, 0, T, 0, X, 8, st, nfl_act_g(NKP, 1), mst, nfl_msk_g(1));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO, NFL_PRODS[NFL_P_IDX_T2]>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 2), mst, nfl_msk_g(2));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO, NFL_PRODS[NFL_P_IDX_T3]>(ring, bias_lds, rt, h, X, 0, X, 0, X, 8, st, nfl_act_g(NKP, 3), mst, nfl_msk_g(3));
+                nfl_dense<NP, NCB, 8, 0, true, 4, 2, STASH, LO, NFL_PRODS[NFL_P_IDX_T4]>(ring, bias_lds, rt, h, X, 8, X, 8, X, 0, st, nfl_act_g(NKP, 4), mst, nfl_msk_g(4));
                 f16v hacc[NCB];
-                nfl_head<NP, NCB, 8>(ring, bias_lds, rt, h, X, 0, hacc);
+                nfl_head<NP, NCB, 8, NFL_PRODS[NFL_P_IDX_THEAD]>(ring, bias_lds, rt, h, X, 0, hacc);
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
@@ -1196,6 +1220,10 @@ static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void
     A.n_points = 0;
     A.emb_stride = 0;
     A.gen_rays = 0;
+    A.nfx_rt = hp->n_emb_xyz;
+    A.ndir_rt = (hp->ld[NFL_P_DIR] - NFL_W - hp->n_a - 3) / 6;
+    A.cx = 6 * A.nfx_rt + 3;
+    A.cd = 6 * A.ndir_rt + 3;
     memset(&A.cam, 0, sizeof(A.cam));
     if ((args->h_cam != nullptr || args->d_cam != nullptr) && MODE != NFL_MODE_EMBED) {
         A.gen_rays = 1;
@@ -1237,6 +1265,10 @@ static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void
 template <int NSPLIT, int NCB, int NFX>
 static int nfl_launch_render(const NflPlan* hp, const void* d_plan, const void* d_packed,
                              const nfl_pass_args* args, hipStream_t stream) {
+#ifdef NFL_DIAG_INFERENCE_ONLY      // sweep builds (nfl_diag.h): only the inference instantiation is compiled
+    if (args->d_embedded || args->d_act_stash) return NFL_EINVAL;
+    return nfl_launch_render_t<NSPLIT, NCB, NFX, NFL_MODE_RENDER>(hp, d_plan, d_packed, args, stream);
+#endif
     if (args->d_embedded) return nfl_launch_render_t<NSPLIT, NCB, NFX, NFL_MODE_EMBED>(hp, d_plan, d_packed, args, stream);
     if (args->d_act_stash) {
         if (NSPLIT != 3) return NFL_EINVAL;        // the training stash is written by the accurate mode only

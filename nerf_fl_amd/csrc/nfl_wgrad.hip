@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "../../include/nerf_fl_amd.h"
+#include "nfl_diag.h"
 #include "nfl_plan.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -452,7 +453,7 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
     if (!d || !h_plan) return NFL_EINVAL;
     if (bytes < sizeof(WgPlan)) return NFL_ESMALL;
     if (nfl_plan_fill(d, NFL_PREC_F16X3, &p) != NFL_OK) return NFL_EINVAL;
-    const int nkp = p.nkp, cx = 6 * d->n_emb_xyz + 3, W = NFL_W, H = NFL_W / 2;
+    const int nkp = p.nkp, cx = 6 * d->n_emb_xyz + 3, cd = 6 * d->n_emb_dir + 3, W = NFL_W, H = NFL_W / 2;
     const bool ut = p.has_t && use_transient;
     WgPlan& P = *static_cast<WgPlan*>(h_plan);
     memset(&P, 0, sizeof(P));
@@ -506,8 +507,8 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
     {   // dir_encoding: the side inputs [dir PE | appearance] (columns 256..) and the bias
         WgJob j = make_job(NFL_P_DIR, p.ld[NFL_P_DIR], true);
         add_tiles(j.ot, j.n_ot, NFL_GRD_DIRH, NFL_SEG_ACT, 0, H);
-        add_tiles(j.it, j.n_it, nfl_act_d(nkp), NFL_SEG_NAT, W, 27);
-        if (p.has_a) add_tiles(j.it, j.n_it, nfl_act_d(nkp) + 2, NFL_SEG_NAT, W + 27, p.n_a);
+        add_tiles(j.it, j.n_it, nfl_act_d(nkp), NFL_SEG_NAT, W, cd);
+        if (p.has_a) add_tiles(j.it, j.n_it, nfl_act_d(nkp) + 2, NFL_SEG_NAT, W + cd, p.n_a);
         push(j);
     }
     {   // rgb head
@@ -635,6 +636,11 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 0, d_gmax);
     if (n_rays == 0) return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
     hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, A);
+#ifdef NFL_DIAG_WGRAD_PASSES
+    const int wg_passes = NFL_DIAG_WGRAD_PASSES;
+#else
+    const int wg_passes = 3;
+#endif
     if (mult == 2) {
         // three-product weight gradient, dW = sum_s (d_hi + d_lo) (x) (h_hi + h_lo) without the lo x lo term: the same
         // streaming GEMM over the residual records, accumulated into the same fp32 tensors (fp16 x fp16 products are exact
@@ -642,11 +648,11 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
         // are sum_s (d_hi + d_lo): the second launch adds its share, the third (h_lo) none.
         WgArgs B = A;
         B.grd = d_grad_stash + (size_t)hp->grd_slots * 1024;
-        hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
+        if (wg_passes >= 2) hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
         B = A;
         B.act = d_act_stash + (size_t)hp->act_slots * 1024;
         B.bias_on = 0;
-        hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
+        if (wg_passes >= 3) hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
     }
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 1, d_gmax);
 

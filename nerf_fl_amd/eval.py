@@ -66,7 +66,10 @@ class GraphedChunk:
         n_xyz, n_dir = rnd._n_freqs(embeddings["xyz"]), rnd._n_freqs(embeddings["dir"])
         self.fields = [rnd._field(m, n_xyz, n_dir, self.device, pack=False) for m in models.values()]
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        import torch.distributed as dist
+        # a process group's watchdog thread may query events while we capture: confine the capture checks to this thread
+        mode = dict(capture_error_mode="thread_local") if dist.is_available() and dist.is_initialized() else {}
+        with torch.no_grad(), torch.cuda.graph(self.graph, **mode):
             self.out = run()
 
     def alive_for(self, models):

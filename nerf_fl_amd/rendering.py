@@ -613,6 +613,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
         da.d_latent_row = _ptr(cfg["ts"])       # the scatter-add into the table gradients happens in the kernel
     if g_rays is not None:
         da.d_g_rays, da.d_rays, da.d_z = _ptr(g_rays), _ptr(rays), _ptr(st["z"])
+        da.dir_is_data = int(cfg["view_dir"] is not None)
         da.d_pe_w_xyz, da.d_pe_w_dir = _ptr(cfg["pe_w_xyz"]), _ptr(cfg["pe_w_dir"])
     bp = field.ensure_bwd_packed(cfg["rays_grad"], cfg["bprec"])
     _lib.check(L.nfl_mlp_dgrad(bp["h"], _ptr(bp["d"]), _ptr(bp["packed"]), C.byref(da), _stream()), "nfl_mlp_dgrad")
@@ -750,9 +751,10 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                 torch.tensor([float(embeddings["xyz"].barf_weight(f, epoch)) for f in embeddings["xyz"].freqs], device=dev)
             cfg["pe_w_dir"] = embeddings["dir"].weights(epoch).to(dev) if hasattr(embeddings["dir"], "weights") else \
                 torch.tensor([float(embeddings["dir"].barf_weight(f, epoch)) for f in embeddings["dir"].freqs], device=dev)
-        if rays_grad and kwargs.get("view_dir") is not None:
-            raise NotImplementedError("gradient w.r.t. rays with a separate view_dir")
         if kwargs.get("view_dir") is not None:
+            if kwargs["view_dir"].requires_grad and torch.is_grad_enabled():
+                raise NotImplementedError("gradient w.r.t. `view_dir` (no caller of the reference asks for it); detach it")
+            # with rays.requires_grad the direction encoding is data then (rendering.py:236-238): dgrad leaves it out of rays.grad
             cfg["view_dir"] = _f32c(kwargs["view_dir"], "view_dir", (R, 3))
         cfg["f_c"] = _field(models["coarse"], n_xyz, n_dir, dev, pack=False)      # packed below, all streams in one launch
         # random draws, in the reference's order (rendering.py:258, 151, 30, 151)

@@ -286,7 +286,11 @@ class GraphedTrainStep:
                                f"steps (first: index {missing[0]}); pass only parameters the step reaches")
         self.graph = torch.cuda.CUDAGraph()
         self.graph_opt = None
-        with torch.cuda.graph(self.graph):
+        # With a process group alive, its watchdog thread polls the events of earlier collectives (hipEventQuery) at any
+        # time; under the default "global" capture mode such a call from ANOTHER thread invalidates the capture
+        # ("operation not permitted when stream is capturing").  thread_local confines the checks to this thread.
+        mode = dict(capture_error_mode="thread_local") if dist.is_initialized() else {}
+        with torch.cuda.graph(self.graph, **mode):
             self.out = fwd_bwd()
             if self.all_reduce and self.captured_collective:
                 reduce()
@@ -294,7 +298,7 @@ class GraphedTrainStep:
                 opt.step()
         if self.all_reduce and not self.captured_collective:
             self.graph_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_opt, pool=self.graph.pool(), **mode):
                 opt.step()
 
     def load(self, rays, ts, target):

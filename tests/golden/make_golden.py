@@ -252,24 +252,25 @@ def train_reference(steps=400, R=512, n_vocab=20, lr=1e-3):
 def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, use_disp=False,
                 perturb=0.0, noise_std=0.0, test_time=False, n_vocab=20, kwargs_mode="ts",
                 output_transient=None, grads=False, rays_grad=False, near=2.0, far=6.0, seed=11,
-                n_emb_xyz=10, barf_epoch=None, rays_kind="blender", view_dir=False, beta_min=0.1):
+                n_emb_xyz=10, barf_epoch=None, rays_kind="blender", view_dir=False, beta_min=0.1, n_emb_dir=4):
     """fine: None | 'base' | 'a' | 'at'.  rays_kind 'photo': per-ray near/far (phototourism); view_dir: pass a
     `view_dir` kwarg that differs from rays_d (rendering.py:236-238)."""
-    spec_c = orc.FieldSpec("coarse", n_emb_xyz=n_emb_xyz)
+    spec_c = orc.FieldSpec("coarse", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir)
     barf = barf_epoch is not None
     mc = ref_field(spec_c, seed, regime, refine_pose=barf)
     models = {"coarse": mc}
     if barf:        # train.py:42-44
-        embeddings = {"xyz": BarfPosEmbedding(n_emb_xyz - 1, n_emb_xyz, 4, 8), "dir": BarfPosEmbedding(3, 4, 4, 8)}
+        embeddings = {"xyz": BarfPosEmbedding(n_emb_xyz - 1, n_emb_xyz, 4, 8),
+                      "dir": BarfPosEmbedding(n_emb_dir - 1, n_emb_dir, 4, 8)}
     else:
-        embeddings = {"xyz": PosEmbedding(n_emb_xyz - 1, n_emb_xyz), "dir": PosEmbedding(3, 4)}
+        embeddings = {"xyz": PosEmbedding(n_emb_xyz - 1, n_emb_xyz), "dir": PosEmbedding(n_emb_dir - 1, n_emb_dir)}
     cfg = dict(R=R, S=S, I=I, fine=fine, regime=regime, white_back=white_back, use_disp=use_disp,
                perturb=perturb, noise_std=noise_std, test_time=test_time, n_vocab=n_vocab,
                kwargs_mode=kwargs_mode, output_transient=output_transient, seed=seed,
-               n_emb_xyz=n_emb_xyz, beta_min=beta_min, barf_epoch=barf_epoch, rays_kind=rays_kind)
+               n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, beta_min=beta_min, barf_epoch=barf_epoch, rays_kind=rays_kind)
     spec_f = None
     if fine is not None:
-        spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, encode_appearance=fine in ("a", "at"),
+        spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, encode_appearance=fine in ("a", "at"),
                                encode_transient=fine == "at", beta_min=beta_min)
         models["fine"] = ref_field(spec_f, seed + 1, regime, refine_pose=barf)
     rays = orc.make_rays_photo(R, seed + 2) if rays_kind == "photo" else orc.make_rays(R, seed + 2, near, far)
@@ -445,6 +446,17 @@ RENDER_CASES = [
                                rays_kind="photo")),
     # G17: weights after a few hundred Adam steps of the reference (train_reference): cfg 2 and cfg 3, forward
     # (deterministic, stochastic, test_time) and gradients
+    # G18: other encoder widths (opt.py:25-28 takes any integer): xyz 6 / dir 2, xyz 12 / dir 4, xyz 3 / dir 1
+    ("g18_emb6_2", dict(R=48, S=32, I=32, fine="at", white_back=True, grads=True, n_emb_xyz=6, n_emb_dir=2, seed=31)),
+    ("g18_emb12_4", dict(R=48, S=32, I=32, fine="base", white_back=False, grads=True, rays_grad=True, n_emb_xyz=12, seed=32)),
+    ("g18_emb6_2_test", dict(R=40, S=64, I=64, fine="at", white_back=False, test_time=True, n_emb_xyz=6, n_emb_dir=2, seed=33,
+                             near=0.3, far=5.0)),
+    ("g18_emb3_1_barf", dict(R=32, S=32, I=32, fine="base", white_back=True, grads=True, rays_grad=True, barf_epoch=6,
+                             n_emb_xyz=3, n_emb_dir=1, seed=34)),
+    ("g18_emb14_3_stoch", dict(R=48, S=64, I=64, fine="a", white_back=True, perturb=1.0, noise_std=1.0, n_emb_xyz=14,
+                               n_emb_dir=3, seed=35)),
+    # view_dir given AND a gradient w.r.t. the rays (rendering.py:236-238: the direction encoding then does not depend on rays)
+    ("g16_view_dir_rays", dict(R=48, S=32, I=32, fine="a", white_back=True, view_dir=True, grads=True, rays_grad=True, seed=36)),
     ("g17_trained_cfg2", dict(R=64, S=64, I=64, fine="base", white_back=True, regime="trained", grads=True, seed=21)),
     ("g17_trained_cfg3", dict(R=64, S=64, I=64, fine="at", white_back=True, regime="trained", grads=True, seed=22)),
     ("g17_trained_cfg3_stoch", dict(R=64, S=64, I=64, fine="at", white_back=True, regime="trained", perturb=1.0,

@@ -113,7 +113,7 @@ def run(kind, perturb=0.0, replica=1, grad_noise=0.0):
 if __name__ == "__main__":
     import re
     for kind in (sys.argv[1:] or ["base", "nerfw"]):
-        m = re.fullmatch(r"(base|nerfw)_(replica|gradnoise)(\d*)", kind)
+        m = re.fullmatch(r"(base|nerfw|smooth)_(replica|gradnoise)(\d*)", kind)
         if m and m.group(2) == "replica":          # base_replica, base_replica2, base_replica3, ...
             run(m.group(1), perturb=1e-6, replica=int(m.group(3) or 1))
         elif m:                                    # base_gradnoise1, ...: the reference with a 1e-3 gradient noise floor

@@ -44,12 +44,12 @@ def load(name):
 
 
 def specs_and_params(cfg):
-    n_emb_xyz = cfg.get("n_emb_xyz", 10)
-    spec_c = orc.FieldSpec("coarse", n_emb_xyz=n_emb_xyz)
+    n_emb_xyz, n_emb_dir = cfg.get("n_emb_xyz", 10), cfg.get("n_emb_dir", 4)
+    spec_c = orc.FieldSpec("coarse", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir)
     P_c = field_params(spec_c, cfg["seed"], cfg["regime"])
     spec_f = P_f = None
     if cfg["fine"] is not None:
-        spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, encode_appearance=cfg["fine"] in ("a", "at"),
+        spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, encode_appearance=cfg["fine"] in ("a", "at"),
                                encode_transient=cfg["fine"] == "at", beta_min=cfg["beta_min"])
         P_f = field_params(spec_f, cfg["seed"] + 1, cfg["regime"])
     return spec_c, P_c, spec_f, P_f

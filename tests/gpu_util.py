@@ -17,11 +17,11 @@ def module_from(spec, P, refine_pose=False):
     return m.to(DEV)
 
 
-def make_embeddings(n_emb_xyz, barf):
+def make_embeddings(n_emb_xyz, barf, n_emb_dir=4):
     if barf:
         from nerf_fl_amd import BarfPosEmbedding
-        return {"xyz": BarfPosEmbedding(n_emb_xyz - 1, n_emb_xyz, 4, 8), "dir": BarfPosEmbedding(3, 4, 4, 8)}
-    return {"xyz": PosEmbedding(n_emb_xyz - 1, n_emb_xyz), "dir": PosEmbedding(3, 4)}
+        return {"xyz": BarfPosEmbedding(n_emb_xyz - 1, n_emb_xyz, 4, 8), "dir": BarfPosEmbedding(n_emb_dir - 1, n_emb_dir, 4, 8)}
+    return {"xyz": PosEmbedding(n_emb_xyz - 1, n_emb_xyz), "dir": PosEmbedding(n_emb_dir - 1, n_emb_dir)}
 
 
 def hip_render(specs, rays, kw, precision="f16x3", field_raw=False):
@@ -32,7 +32,7 @@ def hip_render(specs, rays, kw, precision="f16x3", field_raw=False):
     models = {"coarse": module_from(spec_c, P_c, barf)}
     if spec_f is not None:
         models["fine"] = module_from(spec_f, P_f, barf)
-    emb = make_embeddings(spec_c.n_emb_xyz, barf)
+    emb = make_embeddings(spec_c.n_emb_xyz, barf, spec_c.n_emb_dir)
     extra = {}
     if barf:
         extra["current_epoch"] = kw["barf_epoch"]

@@ -30,6 +30,8 @@ CASES = ["g11_grad_cfg1", "g11_grad_cfg2", "g11_grad_cfg3", "g11_grad_cfg3_ts", 
          "g11_grad_rays", "g14_barf_e6", "g14_barf_e9",      # the last three also check d/d rays (learnable poses)
          "g15_photo_grad", "g15_photo_stoch",                # configs[3]: N_vocab 1500 tables, per-ray near/far, R 1024
          "g16_view_dir",                                     # view_dir kwarg
+         "g16_view_dir_rays",                                # view_dir AND d/d rays (the direction encoding is then data)
+         "g18_emb6_2", "g18_emb12_4", "g18_emb3_1_barf",     # other encoder widths (opt.py:25-28): xyz 6 / dir 2, 12 / 4 (+ rays), 3 / 1 (BARF + rays)
          "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch"]   # weights after 400 reference Adam steps
 
 # thresholds: measure -> (default, {tensor-name substring: override})
@@ -91,7 +93,7 @@ def _run_case(name):
     models = {"coarse": gpu_util.module_from(spec_c, P_c, barf)}
     if spec_f is not None:
         models["fine"] = gpu_util.module_from(spec_f, P_f, barf)
-    emb = gpu_util.make_embeddings(spec_c.n_emb_xyz, barf)
+    emb = gpu_util.make_embeddings(spec_c.n_emb_xyz, barf, spec_c.n_emb_dir)
     extra, leaves = {}, {}
     if barf:
         extra["current_epoch"] = cfg["barf_epoch"]

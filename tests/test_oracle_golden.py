@@ -53,7 +53,7 @@ def test_g3_sample_pdf():
 
 
 RENDER = [n for n in gu.golden_names("g") if n[:2] in ("g4", "g5", "g6", "g7", "g8", "g9")
-          or n.startswith(("g10", "g12", "g13", "g14", "g15", "g16", "g17"))]
+          or n.startswith(("g10", "g12", "g13", "g14", "g15", "g16", "g17", "g18"))]
 
 
 @pytest.mark.parametrize("name", RENDER)
@@ -74,7 +74,8 @@ def test_render_forward(name):
 
 
 GRAD = gu.golden_names("g11_") + ["g12_stoch_grad", "g14_barf_e6", "g14_barf_e9", "g15_photo_grad", "g15_photo_stoch",
-                                   "g16_view_dir", "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch"]
+                                   "g16_view_dir", "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch",
+                                   "g16_view_dir_rays", "g18_emb6_2", "g18_emb12_4", "g18_emb3_1_barf"]
 
 
 @pytest.mark.parametrize("name", GRAD)

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
 RENDER = [n for n in gu.golden_names("g") if n[:2] in ("g4", "g5", "g6", "g7", "g8", "g9")
-          or n.startswith(("g10", "g12_stoch_base", "g12_stoch_nerfw", "g13", "g14_barf_e2", "g15", "g16", "g17"))]
+          or n.startswith(("g10", "g12_stoch_base", "g12_stoch_nerfw", "g13", "g14_barf_e2", "g15", "g16", "g17", "g18"))]
 
 
 # Importance sampling (rendering.py:7-46) is discontinuous / ill-conditioned in the coarse weights: see

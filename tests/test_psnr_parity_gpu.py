@@ -76,32 +76,29 @@ def test_fit_psnr_matches_oracle():
 # validation PSNR; tests/psnr_scene.py regenerates the inputs on both sides).
 # ---------------------------------------------------------------------------------------------------------------------
 # How close can two correct implementations be?  Training is chaotic: the reference, re-run here with its initial
-# weights perturbed by 1e-6 relative (fp32 rounding level; psnr_*_replica*.npz), ends with a validation PSNR that scatters
-# with sigma ~ 0.12 dB around its mean after these 600 steps (base: 21.88 .. 22.21 dB over the stored runs), and the HIP
-# fit -- not deterministic either, its weight gradients are accumulated with fp32 atomics -- scatters by the same amount
-# (21.81 .. 22.32 dB over 27 launches).  One run against one run cannot resolve 0.1 dB (BASELINE.json), so the test
-# compares ENSEMBLES: the mean over N_HIP_RUNS HIP fits against the mean over all stored reference runs, allowing 0.1 dB
-# plus three standard errors of that difference.  Measured: base 22.05 (HIP, 27 runs) vs 22.00 dB (reference, 6 runs).
+# weights perturbed by 1e-6 relative (fp32 rounding level; psnr_*_replica*.npz: twelve stored runs per scene), ends with a
+# validation PSNR that scatters with sigma ~ 0.12 dB around its mean on the base scene (0.02-0.04 dB on the NeRF-W one),
+# and the HIP fit -- not deterministic either, its weight gradients are accumulated with fp32 atomics -- scatters by the
+# same amount.  One run against one run cannot resolve 0.1 dB (BASELINE.json), so the test compares ENSEMBLES: the mean
+# over N_HIP_RUNS HIP fits against the mean over all stored reference runs.  With 12 + 16 runs the standard error of that
+# difference is ~0.045 dB (base) / ~0.012 dB (NeRF-W); the assertion is |difference| <= 0.1 dB + 1.5 standard errors
+# (0.17 / 0.12 dB): a true difference of 0.25 dB fails with probability > 0.95, a correct build passes with > 0.99.
 #
-# Training loss, windowed over 50 steps.  Over the first 100 steps the HIP curve is the reference's (2e-4 per 10-step
-# window, 1e-6 per step: tests/report_psnr_curve.py); later it scatters around it like the reference's own replicas do:
-# base scene -2.4 .. +0.9 % per run in the last window (mean of 8 runs -0.6 %; the replicas' sigma there is 1.3 %),
-# NeRF-W -0.4 % (mid-run -1 %).  The test pins the first 100 steps at 0.5 % and allows 4 % on the mean curve later.
+# Training loss, windowed over 50 steps: the mean HIP curve must lie within three standard errors of the reference's mean
+# curve in EVERY window, the standard error taken from the scatter of the runs themselves (plus 0.05 % for the first
+# windows, where the runs have not separated yet).  On the NeRF-W scene that is +-0.2 .. 0.4 %.
 #
-# History worth keeping.  Until xyz_encoding_final was folded out of the packed streams the HIP curve
-# of the base scene drifted BELOW the reference's in every launch, gradually: -1.5 % around step 300, -3 % around 400,
-# -4 .. -7 % in the last windows, with validation PSNR unaffected.  The hunt (profiles/r02_psnr_drift_control.txt) excluded
-# the forward (loss equal to the fp32 forward's to 1e-7 along a HIP trajectory), the gradients' accuracy (cosine with fp32
-# autograd 1 - 1e-8, worst tensor 4e-3 relative, errors uncorrelated from step to step: tests/report_psnr_fwdcheck.py),
-# the optimizer and the harness (the fp32 oracle trained ON THE GPU follows the CPU reference to 0.5 % with torch's Adam,
-# 0.2 % with this package's: tests/report_psnr_oracle_gpu.py), showed that additive gradient noise of the backward's size
-# produces such a drift in fp32 autograd (a fixed pattern of 3e-4 of each tensor's norm: -5.9 / -6.7 / -6.7 %; fresh white
-# noise: -5.1 .. +0.5 %; multiplicative noise or emulated fp16 roundings of single sites: +-2 %), and ended when the layer
-# left the dgrad stream: with d(h8) computed from the 128-wide head gradients through ONE fp16 matrix (W_dir' = W_dir
-# W_fin) instead of two in a row with an fp16 intermediate and no relu mask between them, the drift is gone while the
-# per-step gradient errors are the size they were.  What exactly in that two-product path biased the trunk's gradients
-# coherently enough for Adam to integrate it was not isolated.
-N_HIP_RUNS = 4
+# What this band caught (round 3).  Until round 3 the dgrad kernel multiplied the gradients by the fp16-ROUNDED transposed
+# weights; the NeRF-W curve then sat -0.4 .. -1.0 % below the reference's from step 250 on, every fit on the same side
+# (3-8 sigma), and a base-scene drift of -4 .. -7 % had been seen in round 2 while xyz_encoding_final was still a layer of
+# the dgrad stream.  profiles/r03_psnr_backward_attribution.txt pins it: the offset is there exactly when the gradient
+# chain sees W_hi instead of W (a fixed-pattern perturbation of the backward operator, identical for every sample of a
+# step and nearly identical from step to step, which Adam integrates), and gone when the chain sees the weights to fp32
+# class -- whether or not gradients and activations are rounded to fp16 (those roundings are fresh per sample and average
+# out).  The default dgrad now reads hi + lo weight fragments (two products); set_precision(backward="f16x3") splits the
+# gradients and the stashes as well (three products everywhere, the reference's fp32 precision class).
+N_HIP_RUNS = {"base": 16, "nerfw": 8, "smooth": 16}
+
 
 
 def fit_64_64(kind, _grad_noise=0.0, _loss="hip", _adam="hip"):
@@ -165,37 +162,47 @@ def reference_runs(kind):
     return [np.load(f, allow_pickle=False) for f in files]
 
 
-@pytest.mark.parametrize("kind", ["base", "nerfw"])
-def test_fit_psnr_matches_reference_64_64(kind):
+@pytest.mark.parametrize("kind,backward", [("base", "f16"), ("nerfw", "f16"), ("nerfw", "f16x3")])
+def test_fit_psnr_matches_reference_64_64(kind, backward):
     import json
 
     import numpy as np
 
+    import nerf_fl_amd
     import psnr_scene as sc
     refs = reference_runs(kind)
-    assert len(refs) >= 3
+    assert len(refs) >= 10
     for r in refs:
         assert json.loads(str(r["cfg"])) == sc.CONFIGS[kind], "a stored reference run was made with other hyper-parameters"
     steps, win = sc.CONFIGS[kind]["steps"], 50
     wmean = lambda x: np.asarray(x, np.float64)[: steps // win * win].reshape(-1, win).mean(1)
     ref_psnr = np.array([float(r["val_psnr"]) for r in refs])
     ref_curves = np.stack([wmean(r["losses"]) for r in refs])
-    runs = [fit_64_64(kind) for _ in range(N_HIP_RUNS)]
+    nerf_fl_amd.set_precision(backward=backward)
+    try:
+        runs = [fit_64_64(kind) for _ in range(N_HIP_RUNS[kind])]
+    finally:
+        nerf_fl_amd.set_precision(backward="f16")
     hip_psnr = np.array([p for _, p in runs])
     hip_curves = np.stack([wmean(l) for l, _ in runs])
-    # validation PSNR: ensemble means, 0.1 dB + 3 standard errors (sample sigmas floored at 0.08 dB: three or four runs
+    # validation PSNR: ensemble means, 0.1 dB + 1.5 standard errors (sample sigmas floored at 0.03 dB: a handful of runs
     # can land close together by chance)
-    s_ref, s_hip = max(ref_psnr.std(ddof=1), 0.08), max(hip_psnr.std(ddof=1), 0.08)
+    s_ref, s_hip = max(ref_psnr.std(ddof=1), 0.03), max(hip_psnr.std(ddof=1), 0.03)
     se = float(np.sqrt(s_ref ** 2 / len(ref_psnr) + s_hip ** 2 / len(hip_psnr)))
     dev_rel = (hip_curves.mean(0) - ref_curves.mean(0)) / ref_curves.mean(0)
-    print(f"[{kind}] validation PSNR: reference {ref_psnr.mean():.3f} dB over {len(refs)} runs ({' '.join(f'{v:.2f}' for v in ref_psnr)}), "
+    # per-window band of the mean loss curve: three standard errors of the difference of the two ensemble means
+    rel_sd = np.maximum(ref_curves.std(0, ddof=1), hip_curves.std(0, ddof=1)) / ref_curves.mean(0)
+    band = 3.0 * rel_sd * np.sqrt(1.0 / len(refs) + 1.0 / len(runs)) + 5e-4
+    print(f"[{kind}, backward {backward}] per-window band (%): {' '.join(f'{100 * v:.2f}' for v in band)}")
+    print(f"[{kind}, backward {backward}] validation PSNR: reference {ref_psnr.mean():.3f} dB over {len(refs)} runs ({' '.join(f'{v:.2f}' for v in ref_psnr)}), "
           f"HIP {hip_psnr.mean():.3f} dB over {len(runs)} runs ({' '.join(f'{v:.2f}' for v in hip_psnr)}); standard error of the "
           f"difference {se:.3f} dB; mean windowed loss curve vs the reference's (%): {' '.join(f'{100 * v:.2f}' for v in dev_rel)}; "
           f"the reference runs among themselves (rel. std, %): {' '.join(f'{100 * v:.2f}' for v in ref_curves.std(0, ddof=1) / ref_curves.mean(0))}")
     for l, _ in runs:
         assert abs(float(l[0]) - float(refs[0]["losses"][0])) <= 1e-4 * max(1.0, abs(float(refs[0]["losses"][0]))), "same first step"
     assert ref_psnr.mean() > 15.0, "the reference fit did not learn anything; the comparison would be vacuous"
-    assert abs(hip_psnr.mean() - ref_psnr.mean()) <= 0.1 + 3.0 * se
+    assert abs(hip_psnr.mean() - ref_psnr.mean()) <= 0.1 + 1.5 * se, (hip_psnr.mean(), ref_psnr.mean(), se)
     assert np.abs(hip_psnr - ref_psnr.mean()).max() <= 0.1 + 5.0 * max(s_ref, s_hip), "a single run far outside the scatter"
-    assert np.abs(dev_rel[:2]).max() <= 0.005, "the first 100 steps follow the reference's curve"
-    assert np.abs(dev_rel).max() <= 0.04
+    assert np.abs(dev_rel[:2]).max() <= 0.002, "the first 100 steps follow the reference's curve"
+    worst = int(np.argmax(np.abs(dev_rel) - band))
+    assert (np.abs(dev_rel) <= band).all(), f"window {worst}: mean loss curve {100 * dev_rel[worst]:+.2f} % vs band {100 * band[worst]:.2f} %"
