@@ -103,11 +103,12 @@ int nfl_pack_field(const void* h_plan, const void* d_plan, const nfl_field_param
 /* xyz_encoding_final is linear and feeds dir_encoding.0 / transient_encoding.0 only, so the packed streams carry no tiles
  * for it: it is folded into the first 256 input columns of those two layers,
  *   W' = [W[:, :256] W_fin | W[:, 256:]],   b' = b + W[:, :256] b_fin.
- * d_wdir_c (128, 256 + 27 + n_a) and d_wt0_c (128, 256 + n_tau; with has_t) must hold COPIES of dir_encoding.0.weight /
+ * n_side = side-input columns of dir_encoding.0 = (6 n_emb_dir + 3) + n_a (0 without the appearance input).
+ * d_wdir_c (128, 256 + n_side) and d_wt0_c (128, 256 + n_tau; with has_t) must hold COPIES of dir_encoding.0.weight /
  * transient_encoding.0.weight on entry (their side columns are kept); d_bdir_c / d_bt0_c (128) are written.  Pack with a
  * nfl_field_params whose weight / bias entries NFL_P_DIR (and NFL_P_T0) point at these folded tensors; every other
  * entry point (nfl_mlp_wgrad's `params`) takes the ORIGINAL parameters.  One launch, fp32 (v_mfma_f32_32x32x2_f32). */
-int nfl_compose_forward(const nfl_field_params* params, int32_t has_t, int32_t n_a, int32_t n_tau,
+int nfl_compose_forward(const nfl_field_params* params, int32_t has_t, int32_t n_side, int32_t n_tau,
                         float* d_wdir_c, float* d_bdir_c, float* d_wt0_c, float* d_bt0_c, void* stream);
 /* Several streams in one launch (a training step re-packs the forward and the dgrad stream of both fields after every
  * optimizer update).  Same argument meaning and checks as nfl_pack_field, per job. */

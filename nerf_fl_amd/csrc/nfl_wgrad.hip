@@ -712,7 +712,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
 // transient_encoding.0.  The caller hands in copies of W_dir / W_t0 (the side columns are kept, the first 256 columns
 // overwritten) and receives the folded biases; nfl_pack_field(s) is then given these in place of the originals, and
 // the streams carry no tiles for xyz_encoding_final (nfl_plan.cpp): one 256 x 256 layer less in the forward and in dgrad.
-extern "C" int nfl_compose_forward(const nfl_field_params* params, int32_t has_t, int32_t n_a, int32_t n_tau,
+extern "C" int nfl_compose_forward(const nfl_field_params* params, int32_t has_t, int32_t n_side, int32_t n_tau,
                                    float* d_wdir_c, float* d_bdir_c, float* d_wt0_c, float* d_bt0_c, void* stream) {
     if (!params || !d_wdir_c || !d_bdir_c || (has_t && (!d_wt0_c || !d_bt0_c))) return NFL_EINVAL;
     const float* Wf = params->weight[NFL_P_FINAL];
@@ -730,7 +730,7 @@ extern "C" int nfl_compose_forward(const nfl_field_params* params, int32_t has_t
     };
     for (int which = 0; which < (has_t ? 2 : 1); ++which) {
         const int L = which ? NFL_P_T0 : NFL_P_DIR;
-        const int ld = W + (which ? n_tau : 27 + n_a);
+        const int ld = W + (which ? n_tau : n_side);
         const float* Ws = params->weight[L];
         WgGemm g;
         memset(&g, 0, sizeof(g));          // W'[r, i] = sum_j W[r, j] W_fin[j, i]   (rows of W are not 16-byte aligned: scalar loads)

@@ -287,7 +287,8 @@ class _PackedField:
             self.fold[n][0].copy_(params[n + ".weight"].detach())        # the side columns ride along; the first 256 are overwritten
         wd, bd = self.fold["dir_encoding.0"]
         wt, bt = self.fold["transient_encoding.0"] if has_t else (None, None)
-        _lib.check(_lib.lib().nfl_compose_forward(C.byref(fp), int(has_t), int(self.desc.n_a if self.desc.encode_appearance else 0),
+        n_side = 6 * int(self.desc.n_emb_dir) + 3 + int(self.desc.n_a if self.desc.encode_appearance else 0)
+        _lib.check(_lib.lib().nfl_compose_forward(C.byref(fp), int(has_t), n_side,
                                                   int(self.desc.n_tau), _ptr(wd), _ptr(bd), _ptr(wt), _ptr(bt), _stream()),
                    "nfl_compose_forward")
         for n in names:
