@@ -20,27 +20,23 @@
 // reduced over the samples of the ray with wave shuffles and accumulated with fp32 atomics.
 #include "nfl_render_impl.h"
 
-// The WEIGHTS the chain delta_{l-1} = W_l^T delta_l multiplies by must not carry a rounding error that persists from
-// step to step.  W_hi = fp16(W) alone is the same wrong matrix for every sample of a step and, once the learning rate has
-// decayed, for hundreds of steps in a row -- a fixed-pattern perturbation of the backward operator that Adam integrates
-// into a systematic offset of the training curve (measured with variant builds: profiles/r03_psnr_backward_attribution.txt:
-// the offset is there exactly when the chain sees W_hi, whatever the gradients' and activations' own roundings, which are
-// fresh per sample and average out).  Two remedies, one per backward arithmetic; the stream holds 2 KiB per k-step in both:
-//   NP = 1 (default, NFL_PREC_F16): one product W_hi d_hi on ERROR-FEEDBACK weights -- every re-pack rounds W plus the
-//     left-over of the previous pack's rounding and keeps the new left-over in the second KiB of the k-step (nfl_pack.hip),
-//     so hi_t - W_t is a first difference with no persistent component.  The kernel DMAs the hi halves only (1 KiB per
-//     k-step in LDS).  Two 32-sample segments (column blocks) per wave and two row tiles per ring chunk: a row tile is
-//     only 16 MFMAs per column block, so the per-tile fixed costs (barrier, weight DMA, LDS reads of the A fragments) are
-//     shared; the register file holds it because the walk needs only TWO 16-k-step operand sets (P, Q below).
-//   NP = 2 (opt-in, NFL_PREC_F16X3): the exact split [hi | lo], gradients split hi + lo as well, three products (the
-//     forward's f16x3 arithmetic), split gradient stash; the operand sets are twice as large, so one segment per wave and
-//     one row tile per chunk.
+// Both kernels stream hi + lo fp16 fragments of the transposed weights (2 KiB per k-step, one row tile per ring chunk):
+// the chain delta_{l-1} = W_l^T delta_l must see the WEIGHTS to fp32 class.  W_hi alone is the same wrong matrix for every
+// sample of a step and nearly the same from step to step -- a fixed-pattern perturbation of the backward operator that Adam
+// integrates into a systematic offset of the training curve (measured: profiles/r03_psnr_backward_attribution.txt), while
+// the roundings of the gradients themselves are fresh per sample and average out.
+//   NP = 1 (default backward, NFL_PREC_F16): gradients as single fp16 images, two products W_hi d_hi + W_lo d_hi; two
+//     32-sample segments (column blocks) per wave, so the per-tile fixed costs (barrier, weight DMA, LDS reads of the A
+//     fragments) are shared by 64 samples; the register file holds it because the walk needs only TWO 16-k-step operand
+//     sets (P, Q below).
+//   NP = 2 (opt-in, NFL_PREC_F16X3): gradients split hi + lo as well, three products (the forward's f16x3 arithmetic),
+//     split gradient stash; the operand sets are twice as large, so one segment per wave.
 #define DG_NCB(NP) ((NP) == 1 ? 2 : 1)
-#define DG_TPC(NP) ((NP) == 1 ? 2 : 1)
+#define DG_TPC(NP) 1
 #ifdef NFL_DIAG_X3_PRODS
-#define DG_PRODS(NP) ((NP) == 1 ? 0 : NFL_DIAG_X3_PRODS)
+#define DG_PRODS(NP) ((NP) == 1 ? 5 : NFL_DIAG_X3_PRODS)
 #else
-#define DG_PRODS(NP) ((NP) == 1 ? 0 : 3)
+#define DG_PRODS(NP) ((NP) == 1 ? 5 : 3)      // nfl_tile_p: bit 2 = hi + lo weight fragments under single-image operands
 #endif
 
 struct DgradArgs {
@@ -66,9 +62,8 @@ template <int NFX, int NP_>
 struct NflDgradCfg {
     static constexpr int NP = NP_, NCB = DG_NCB(NP_), TPC = DG_TPC(NP_);
     static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
-    static constexpr int KSB = 1024 * NP;                // bytes of a k-step IN LDS (NP 1: the hi halves only)
-    static constexpr int SRCMUL = 2 / NP;                // the stream holds 2 KiB per k-step either way
-    static constexpr int MAXKS = TPC * 17;               // row tiles per chunk (NP 1: one barrier per pair of tiles)
+    static constexpr int KSB = 2048;                     // hi + lo weight fragments in both kernels
+    static constexpr int MAXKS = TPC * 17;               // one row tile per chunk
     static constexpr int WBYTES = MAXKS * KSB;
     static constexpr int AUXB = 4 * NCB * 1024;
     static constexpr int SLOT = WBYTES + AUXB;
@@ -80,7 +75,7 @@ struct NflDgradCfg {
 // ring with the per-wave mask pieces: pieces 0..MAXPW-1 are weights, the next one per column block the 1 KiB
 // (four dwords per lane) of that segment's relu-mask words for a group of four tiles, issued with the group's
 // first tile only
-template <int SLOT_BYTES, int WBYTES, int MAXPW, int NCB, int SRCMUL>
+template <int SLOT_BYTES, int WBYTES, int MAXPW, int NCB>
 struct NflRingAux {
     static constexpr int MAXP = MAXPW + NCB;
     const char* gsrc;
@@ -112,7 +107,7 @@ struct NflRingAux {
         n_aux = __builtin_amdgcn_readfirstlane(chunk_aux[c_issue]);
     }
     NFL_DEV void begin_issue() {
-        i_nbytes = (n_off1 - n_off0) / SRCMUL;           // bytes of the chunk in LDS (SRCMUL 2: every other KiB of the stream)
+        i_nbytes = n_off1 - n_off0;
         i_src = gsrc + n_off0;
         i_dst = lds + s_issue * SLOT_BYTES;
         const int slot = n_aux < 0 ? 0 : n_aux;
@@ -139,7 +134,7 @@ struct NflRingAux {
             unsigned byte = (unsigned)(wave + 4 * P) * 1024u;
             const unsigned last = (unsigned)i_nbytes - 1024u;
             byte = byte < last ? byte : last;
-            const unsigned vo = byte * SRCMUL + (threadIdx.x & 63) * 16u;
+            const unsigned vo = byte + (threadIdx.x & 63) * 16u;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(i_src + vo),
                 (__attribute__((address_space(3))) void*)(i_dst + byte), 16, 0, 0);
@@ -438,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     const float scale = nfl_loss_scale_from_bits(nfl_gmax_bits(a.d_gmax));
     const float inv_scale = 1.0f / scale;
 
-    NflRingAux<C::SLOT, C::WBYTES, C::MAXP, NCB, C::SRCMUL> ring;
+    NflRingAux<C::SLOT, C::WBYTES, C::MAXP, NCB> ring;
     ring.gsrc = A.packed;
     ring.chunk_off = chk_lds;
     ring.chunk_aux = aux_lds;

@@ -100,23 +100,10 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(const PackBatch B) {
     }
     if (P.elem == 0) {
         h8 hi, lo;
-        // dgrad stream of the default backward: error feedback across re-packs.  The second KiB of the k-step holds what
-        // the previous pack's rounding left over (zero in a fresh buffer); it is added before this rounding, and the new
-        // left-over replaces it: hi_t = fp16(W_t + c_{t-1}), c_t = W_t + c_{t-1} - hi_t.  Then hi_t - W_t = c_{t-1} - c_t, a
-        // first difference: over any run of steps the weights the gradient chain multiplies by average to the fp32 weights
-        // (to |c| <= half an fp16 ulp divided by the number of steps) instead of repeating one rounding pattern.
-        const bool feedback = P.is_bwd && P.prec == NFL_PREC_F16;
-        h8 carry;
-        if (feedback) carry = *reinterpret_cast<const h8*>(dst + 1024);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t = w[j];
-            if (feedback) {
-                const float c = (float)carry[j];
-                if (fabsf(c) <= 0.001f * fabsf(t) + 1e-7f) t += c;       // a stale carry (weights replaced wholesale) is dropped
-            }
-            hi[j] = (_Float16)t;
-            lo[j] = (_Float16)(t - (float)hi[j]);
+            hi[j] = (_Float16)w[j];
+            lo[j] = (_Float16)(w[j] - (float)hi[j]);
         }
         *reinterpret_cast<h8*>(dst) = hi;
         if (P.nsplit == 3) *reinterpret_cast<h8*>(dst + 1024) = lo;

@@ -118,16 +118,12 @@ static int check_desc(const nfl_field_desc* d) {
 extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, int bwd_prec, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
     if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
-    // Transposed weights as fp16 fragments, 2 KiB per k-step for BOTH backward arithmetics; gradients loss-scaled
-    // (nfl_loss_scale_from_bits).  `prec` records which kernel reads the stream and what the second KiB of a k-step holds:
-    //   NFL_PREC_F16X3: [hi | lo], the exact split, both halves read (three products; one row tile per ring chunk);
-    //   NFL_PREC_F16:   [hi | carry], hi = fp16(W + carry of the previous pack), carry = what that rounding left over --
-    //     first-order error feedback ACROSS re-packs (nfl_pack.hip).  The kernel reads the hi halves only (one product, two
-    //     row tiles per chunk); the rounding error of the weights it multiplies by then has no component that persists
-    //     from step to step, which is the component an optimizer integrates (nfl_dgrad.hip, file header).
+    // hi + lo fp16 fragments of the transposed weights for BOTH backward arithmetics (the chain needs the weights to fp32
+    // class: nfl_dgrad.hip); gradients loss-scaled (nfl_loss_scale_from_bits).  One row tile per chunk (two 2 KiB-per-
+    // k-step tiles would not fit a ring slot).  `prec` records which kernel reads the stream.
     common_init(d, NFL_PREC_F16X3, p);
     p->prec = bwd_prec;
-    const bool pair = bwd_prec == NFL_PREC_F16;
+    const bool pair = false;
     p->elem = 0;
     p->is_bwd = 1;
     const int cx = 6 * d->n_emb_xyz + 3, cd = 6 * d->n_emb_dir + 3;

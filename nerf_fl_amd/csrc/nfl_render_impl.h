@@ -387,10 +387,12 @@ NFL_DEV void nfl_lds_wait(nfl_u4 (&w)[NWP]) {
 // bit 0: w_lo x_hi (the weights' fp16 residuals; without it the layer's weights are fp16-rounded and their lo fragments
 // are not even read from LDS), bit 1: w_hi x_lo (the activations' residuals).  3 = the full f16x3 product.  The per-layer
 // plan is NFL_PRODS (nfl_prods.h), chosen by measurement against the parity bar (tests/report_parity.py).
+// bit 2 (NP == 1 only): the stream carries hi + lo WEIGHT fragments although the B operands are single fp16 images -- the
+// default dgrad (nfl_dgrad.hip): W_hi d_hi + W_lo d_hi, the weights to fp32 class, the gradients fp16.
 template <int PRODS, int NP, int NCB, int NK, int P0, class V8, class GetB, class Epi, class Ring,
-          int DEPTH = (NP == 1 ? 4 : NFL_DEPTH_X3)>
+          int DEPTH = ((NP == 1 && (PRODS & 4) == 0) ? 4 : NFL_DEPTH_X3)>
 NFL_DEV void nfl_tile_p(f16v (&acc)[NCB], const char* wl, const int frag0, GetB&& getb, Epi&& epi, Ring& ring) {
-    constexpr int NWP = NP;               // weight fragments per k-step in LDS: hi (+ lo)
+    constexpr int NWP = (NP == 2 || (PRODS & 4) != 0) ? 2 : 1;          // weight fragments per k-step: hi (+ lo)
     constexpr int KSB = 1024 * NWP;
     constexpr int NW = DEPTH + 1;
     constexpr bool W_LO = NWP == 2 && (PRODS & 1) != 0, X_LO = NP == 2 && (PRODS & 2) != 0;

@@ -241,9 +241,8 @@ class _PackedField:
             h = C.create_string_buffer(nbytes)
             _lib.check(L.nfl_bwd_plan_build(C.byref(self.desc), rg[0], bprec, h, nbytes), "nfl_bwd_plan_build")
             pb = L.nfl_bwd_packed_bytes(C.byref(self.desc), rg[0], bprec)
-            # zero-initialised: the default backward's stream carries the rounding left-over from pack to pack (nfl_pack.hip)
             self.bplans[rg] = dict(h=h, d=torch.frombuffer(bytearray(h.raw), dtype=torch.uint8).to(self.device),
-                                   packed=torch.zeros(pb, dtype=torch.uint8, device=self.device), nbytes=pb, key=None)
+                                   packed=torch.empty(pb, dtype=torch.uint8, device=self.device), nbytes=pb, key=None)
         return self.bplans[rg]
 
     def ensure_bwd_packed(self, rays_grad=False, bprec=None):
