@@ -76,8 +76,9 @@ def parse_args(argv=None):
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
                     help="after the timed steps: keep stepping for this long with one HIP-event pair per step and report "
                          "median / p90 (`sustained`); 0 = off")
-    ap.add_argument("--backward", default="f16", choices=["f16", "f16x3"],
-                    help="arithmetic of the MLP backward: f16 = single fp16 product (default), f16x3 = split operands, "
+    ap.add_argument("--backward", default="f16", choices=["f16", "f16w", "f16x3"],
+                    help="arithmetic of the MLP backward: f16 = single fp16 product (default), f16w = the gradient chain reads "
+                         "hi+lo weight fragments (two products: no systematic training-curve offset), f16x3 = split operands, "
                          "3 products, hi+lo stashes (fp32-class, the reference's precision class)")
     return ap.parse_args(argv)
 
@@ -332,38 +333,44 @@ def run_rank(args):
         n_sus = max(100, int(args.sustained_seconds / max(elapsed / args.steps, 1e-6)) + 1)
         sustained = event_timed(step, n_sus)
         sync()
-    # the same step with the three-product (fp32-class) MLP backward: the reference differentiates in fp32
-    # (train.py:158-174), the default backward here multiplies in fp16; this is the train-step figure at the reference's
-    # precision class, measured on the same batch right after the default one (same K / W)
-    fp32_class = None
+    # The same step with the other two backward arithmetics, measured on the same batch right after the default one (same
+    # K / W).  The reference differentiates in fp32 (train.py:158-174); the default backward here multiplies in fp16.
+    #   f16w : the gradient chain reads hi + lo weight fragments -- no systematic training-curve offset
+    #   f16x3: operands split everywhere, three products, split stashes -- the train-step figure at the reference's
+    #          precision class (`value_fp32_class`)
+    other_modes = {}
     if args.mode == "train" and args.precision == "f16x3" and args.backward == "f16" and not args.no_extras:
-        nerf_fl_amd.set_precision(backward="f16x3")
-        step3 = train_step
-        if args.graph:
-            graphed3 = GraphedTrainStep(models, emb, params, opt, loss_fn if args.unfused_loss else None, rays, ts, target,
-                                        N_SAMPLES, N_IMPORTANCE, white_back=white_back, all_reduce=dist is not None,
-                                        arena=arena, force_all_reduce=force)
-            step3 = graphed3.replay
-        for _ in range(args.warmup):
-            step3()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step3()
-        sync()
-        e3 = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([e3], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e3 = float(t.item())
-        fp32_class = {"value": R * (N_SAMPLES + N_IMPORTANCE) * n_ranks * args.steps / e3, "ms_per_step": 1e3 * e3 / args.steps,
-                      "dtype": "f16x3 fwd + f16x3 bwd",
-                      "backward_arithmetic": "fp16 MFMA, weights / activations / gradients split hi+lo, 3 products, fp32 accumulate; "
-                                             "hi+lo activation and gradient stashes (2x the bytes); gradients returned in fp32"}
-        if args.sustained_seconds > 0:
-            fp32_class["sustained"] = event_timed(step3, max(100, int(args.sustained_seconds / max(e3 / args.steps, 1e-6)) + 1))
+        descr = {"f16w": "as the default (fp16 MFMA, 1 product, fp16 stashes, loss scale) but the gradient chain W^T delta reads "
+                         "hi+lo weight fragments (2 products): weights to fp32 class in the chain",
+                 "f16x3": "fp16 MFMA, weights / activations / gradients split hi+lo, 3 products, fp32 accumulate; "
+                          "hi+lo activation and gradient stashes (2x the bytes); gradients returned in fp32"}
+        for mode in ("f16w", "f16x3"):
+            nerf_fl_amd.set_precision(backward=mode)
+            stepm = train_step
+            if args.graph:
+                gm = GraphedTrainStep(models, emb, params, opt, loss_fn if args.unfused_loss else None, rays, ts, target,
+                                      N_SAMPLES, N_IMPORTANCE, white_back=white_back, all_reduce=dist is not None,
+                                      arena=arena, force_all_reduce=force)
+                stepm = gm.replay
+            for _ in range(args.warmup):
+                stepm()
             sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                stepm()
+            sync()
+            em = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([em], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                em = float(t.item())
+            other_modes[mode] = {"value": R * (N_SAMPLES + N_IMPORTANCE) * n_ranks * args.steps / em, "ms_per_step": 1e3 * em / args.steps,
+                                 "dtype": f"f16x3 fwd + {mode} bwd", "backward_arithmetic": descr[mode]}
+            if args.sustained_seconds > 0:
+                other_modes[mode]["sustained"] = event_timed(stepm, max(100, int(args.sustained_seconds / max(em / args.steps, 1e-6)) + 1))
+                sync()
         nerf_fl_amd.set_precision(backward="f16")
+    fp32_class = other_modes.get("f16x3")
     sync_diff = None
     if dist is not None:
         # data parallelism keeps the replicas identical: same seeded weights, the same averaged gradients, the same Adam.
@@ -398,6 +405,8 @@ def run_rank(args):
         "sustained": sustained,
         "value_fp32_class": None if fp32_class is None else fp32_class["value"],
         "fp32_class": fp32_class,
+        "value_exact_weight_chain": None if "f16w" not in other_modes else other_modes["f16w"]["value"],
+        "exact_weight_chain": other_modes.get("f16w"),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -414,6 +423,7 @@ def run_rank(args):
                    "backward_arithmetic": ("fp16 MFMA, 1 product, fp32 accumulate, fp16 activation/gradient stashes "
                                            "under a device-chosen power-of-two loss scale; gradients returned in fp32"
                                            if args.backward == "f16" else
+                                           "as f16, the gradient chain reading hi+lo weight fragments (2 products)" if args.backward == "f16w" else
                                            "fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate, hi+lo stashes (f16x3)"),
                    "mlp_evals_per_ray": N_SAMPLES + F, "hip_graph": bool(args.graph)},
     }

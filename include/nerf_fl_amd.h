@@ -46,7 +46,9 @@ enum {
 
 enum {
     NFL_PREC_F16X3 = 0,   /* fp16 MFMA, operands split hi+lo, 3 products: ~2^-21 relative, fp32-class (default) */
-    NFL_PREC_F16   = 1    /* fp16 MFMA, single product: ~2^-11 relative (fast mode)                               */
+    NFL_PREC_F16   = 1,   /* fp16 MFMA, single product: ~2^-11 relative (fast mode)                               */
+    NFL_PREC_F16W  = 2    /* BACKWARD only (bwd_prec): as NFL_PREC_F16, but the gradient chain multiplies by hi + lo weight
+                             fragments (two products, the weights to fp32 class): no systematic training-curve offset   */
 };
 
 /* One field (reference class NeRF, models/nerf.py:80-151).  W=256, D=8,
@@ -247,10 +249,16 @@ int nfl_gen_rays(const float* h_c2w, float fx, float fy, float cx, float cy, int
  *   max|head gradient| (d_gmax, written by nfl_composite_backward) so that fp16's range is
  *   used whatever the loss magnitude; the scale is divided out before anything is returned.
  *
- *   bwd_prec selects the arithmetic of that MLP part: NFL_PREC_F16 (default: one fp16 product, gradients within a few 1e-3
- *   of fp32 autograd) or NFL_PREC_F16X3 -- the forward's split-operand arithmetic (hi + lo weight fragments, activations
- *   and gradients, three products: fp32-class, the precision class of the reference's autograd); the stashes then hold a
- *   second, residual record per segment (twice the bytes), written by a forward pass with nfl_pass_args::stash_split = 1.
+ *   bwd_prec selects the arithmetic of that MLP part (profiles/r03_psnr_backward_attribution.txt):
+ *     NFL_PREC_F16   (default) one fp16 product everywhere: gradients within a few 1e-3 of fp32 autograd per step, fastest;
+ *                    the fp16-rounded transposed weights of the chain leave a small systematic offset in long training
+ *                    curves (-0.4 .. -1 % of the late training loss on the NeRF-W parity scene; validation PSNR unaffected);
+ *     NFL_PREC_F16W  the chain delta_{l-1} = W_l^T delta_l reads hi + lo weight fragments (two products): that offset is
+ *                    gone (curve within the reference's own run-to-run scatter); stashes and weight gradients as F16;
+ *     NFL_PREC_F16X3 the forward's split-operand arithmetic throughout (hi + lo weights, activations and gradients, three
+ *                    products, weight gradients from three GEMM passes): fp32-class gradients, the precision class of the
+ *                    reference's autograd; the stashes then hold a second, residual record per segment (twice the bytes),
+ *                    written by a forward pass with nfl_pass_args::stash_split = 1.
  *   One value must be used for the stash sizes, the forward pass, the dgrad plan / stream and nfl_mlp_wgrad of a step. */
 size_t nfl_act_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples, int32_t bwd_prec);
 size_t nfl_grad_stash_bytes(const nfl_field_desc* desc, int32_t n_rays, int32_t n_samples, int32_t bwd_prec);

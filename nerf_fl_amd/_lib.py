@@ -16,6 +16,7 @@ NFL_ABI_VERSION = 8
 NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
+NFL_PREC_F16W = 2      # backward only: one-product arithmetic, but the gradient chain reads hi + lo weight fragments
 NFL_STATUS_NONFINITE = 1
 NFL_STATUS_RANGE = 2
 NFL_NUM_LAYERS = 19

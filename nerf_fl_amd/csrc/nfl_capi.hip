@@ -38,7 +38,7 @@ static size_t n_segments(int32_t n_rays, int32_t n_samples) {
     return (size_t)n_rays * (size_t)((n_samples + 31) / 32);
 }
 size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples, int32_t bwd_prec) {
-    if (!d || n_rays < 0 || n_samples < 1 || (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3)) return 0;
+    if (!d || n_rays < 0 || n_samples < 1 || bwd_prec < 0 || bwd_prec > NFL_PREC_F16W) return 0;
     if (d->n_emb_xyz < 1 || d->n_emb_xyz > NFL_MAX_EMB_XYZ) return 0;
     const int nkp = nfl_nkp_for(d->n_emb_xyz);
     const int mult = bwd_prec == NFL_PREC_F16X3 ? 2 : 1;
@@ -46,7 +46,7 @@ size_t nfl_act_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_sa
     return nfl_msk_offset(n_segments(n_rays, n_samples), nkp, mult) + n_segments(n_rays, n_samples) * NFL_MSK_WORDS * 256;
 }
 size_t nfl_grad_stash_bytes(const nfl_field_desc* d, int32_t n_rays, int32_t n_samples, int32_t bwd_prec) {
-    if (!d || n_rays < 0 || n_samples < 1 || (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3)) return 0;
+    if (!d || n_rays < 0 || n_samples < 1 || bwd_prec < 0 || bwd_prec > NFL_PREC_F16W) return 0;
     const int mult = bwd_prec == NFL_PREC_F16X3 ? 2 : 1;
     return (n_segments(n_rays, n_samples) + 1) * NFL_GRD_SLOTS * mult * 1024 + 4096;   // + one scratch record for padded segments
 }

@@ -20,24 +20,30 @@
 // reduced over the samples of the ray with wave shuffles and accumulated with fp32 atomics.
 #include "nfl_render_impl.h"
 
-// Both kernels stream hi + lo fp16 fragments of the transposed weights (2 KiB per k-step, one row tile per ring chunk):
-// the chain delta_{l-1} = W_l^T delta_l must see the WEIGHTS to fp32 class.  W_hi alone is the same wrong matrix for every
-// sample of a step and nearly the same from step to step -- a fixed-pattern perturbation of the backward operator that Adam
-// integrates into a systematic offset of the training curve (measured: profiles/r03_psnr_backward_attribution.txt), while
-// the roundings of the gradients themselves are fresh per sample and average out.
-//   NP = 1 (default backward, NFL_PREC_F16): gradients as single fp16 images, two products W_hi d_hi + W_lo d_hi; two
-//     32-sample segments (column blocks) per wave, so the per-tile fixed costs (barrier, weight DMA, LDS reads of the A
-//     fragments) are shared by 64 samples; the register file holds it because the walk needs only TWO 16-k-step operand
-//     sets (P, Q below).
-//   NP = 2 (opt-in, NFL_PREC_F16X3): gradients split hi + lo as well, three products (the forward's f16x3 arithmetic),
-//     split gradient stash; the operand sets are twice as large, so one segment per wave.
-#define DG_NCB(NP) ((NP) == 1 ? 2 : 1)
-#define DG_TPC(NP) 1
+// Three arithmetics, one kernel template (M = DgMode<NP, NWP>: parts of a gradient operand, fragments of a weight k-step):
+//   <1, 1>  NFL_PREC_F16 (default): W_hi d_hi, one product.  Two 32-sample segments (column blocks) per wave and two row
+//           tiles per ring chunk: a row tile is only 16 MFMAs per column block, so the per-tile fixed costs (barrier, weight
+//           DMA, LDS reads of the A fragments) are shared; the register file holds it because the walk needs only TWO
+//           16-k-step operand sets (P, Q below).  Fastest; but W_hi is the same wrong matrix for every sample of a step and,
+//           once the learning rate has decayed, for hundreds of steps in a row -- a fixed-pattern perturbation of the
+//           backward operator that Adam integrates into a small systematic offset of long training curves
+//           (profiles/r03_psnr_backward_attribution.txt: the offset is there exactly when the chain sees W_hi, whatever the
+//           gradients' and activations' own roundings, which are fresh per sample and average out).
+//   <1, 2>  NFL_PREC_F16W: W_hi d_hi + W_lo d_hi -- the chain sees the weights to fp32 class, the gradients stay single
+//           fp16 images (stashes as above).  2 KiB per k-step, so one row tile per chunk.  The offset is gone.
+//   <2, 2>  NFL_PREC_F16X3: gradients split hi + lo as well, three products (the forward's f16x3 arithmetic), split
+//           gradient stash; the operand sets are twice as large, so one segment per wave.
+template <int NP_, int NWP_>
+struct DgMode {
+    static constexpr int NP = NP_, NWP = NWP_;
+    static constexpr int NCB = NP_ == 1 ? 2 : 1;
+    static constexpr int TPC = NWP_ == 1 ? 2 : 1;
 #ifdef NFL_DIAG_X3_PRODS
-#define DG_PRODS(NP) ((NP) == 1 ? 5 : NFL_DIAG_X3_PRODS)
+    static constexpr int PRODS = NP_ == 2 ? NFL_DIAG_X3_PRODS : (NWP_ == 2 ? 5 : 0);
 #else
-#define DG_PRODS(NP) ((NP) == 1 ? 5 : 3)      // nfl_tile_p: bit 2 = hi + lo weight fragments under single-image operands
+    static constexpr int PRODS = NP_ == 2 ? 3 : (NWP_ == 2 ? 5 : 0);     // nfl_tile_p: bit 2 = hi + lo weight fragments under single-image operands
 #endif
+};
 
 struct DgradArgs {
     const NflPlan* plan;
@@ -58,12 +64,12 @@ NFL_DEV NflDgKArgs nfl_dg_kargs() {
     return p;
 }
 
-template <int NFX, int NP_>
+template <int NFX, class M>
 struct NflDgradCfg {
-    static constexpr int NP = NP_, NCB = DG_NCB(NP_), TPC = DG_TPC(NP_);
+    static constexpr int NP = M::NP, NCB = M::NCB, TPC = M::TPC;
     static constexpr int NKP = (6 * NFX + 3 + 15) / 16;
-    static constexpr int KSB = 2048;                     // hi + lo weight fragments in both kernels
-    static constexpr int MAXKS = TPC * 17;               // one row tile per chunk
+    static constexpr int KSB = 1024 * M::NWP;            // bytes of a weight k-step: hi (+ lo)
+    static constexpr int MAXKS = TPC * 17;               // row tiles per chunk
     static constexpr int WBYTES = MAXKS * KSB;
     static constexpr int AUXB = 4 * NCB * 1024;
     static constexpr int SLOT = WBYTES + AUXB;
@@ -276,13 +282,13 @@ struct DgEpi {
 
 // NRT transposed row tiles (two per chunk) with up to three K segments.  TS: k-steps a tile occupies in the stream
 // (more than the NK it reads when a pass leaves out the transient head's segment of the d(feat) tiles)
-template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, int NP, int TS = NKA + NKB + NKC, int NA, int NB, int NC, int NOUT, class Ring>
+template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, class M, int TS = NKA + NKB + NKC, int NA, int NB, int NC, int NOUT, class Ring>
 NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
-                      const h8 (&inA)[NA][NCB][NP], int ksA, const h8 (&inB)[NB][NCB][NP], int ksB,
-                      const h8 (&inC)[NC][NCB][NP], int ksC,
-                      h8 (&out)[NOUT][NCB][NP], int out_ks0, char* const (&gst)[NCB], int slot0) {
+                      const h8 (&inA)[NA][NCB][M::NP], int ksA, const h8 (&inB)[NB][NCB][M::NP], int ksB,
+                      const h8 (&inC)[NC][NCB][M::NP], int ksC,
+                      h8 (&out)[NOUT][NCB][M::NP], int out_ks0, char* const (&gst)[NCB], int slot0) {
     constexpr int NK = NKA + NKB + NKC;
-    constexpr int TPC = DG_TPC(NP);
+    constexpr int NP = M::NP, TPC = M::TPC;
     f16v acc[2][NCB];
     unsigned mk[2][NCB];
     unsigned mkq[NCB][4];       // the four mask words of the current group of tiles (arrive with its first tile)
@@ -313,11 +319,11 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         }
         if constexpr (i > 0) {
             DgEpi<MASK, NOUT, NCB, NP> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
-            nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
+            nfl_tile_p<M::PRODS, NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
             ring.note(2 * NCB * NP);     // the epilogue's stash stores, issued at the tile's last k-step
         } else {
             NflNoEpi epi;
-            nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
+            nfl_tile_p<M::PRODS, NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
         }
         // pieces the chunk's k-loops did not get to (piece P0 + k is issued at k-step k of its tile)
         if constexpr (TPC == 1) ring.template pieces<NK, Ring::MAXP>();
@@ -330,8 +336,8 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
 }
 
 // one tile whose rows are latent inputs: sum over the 32 samples of each segment, add to its ray's gradient
-template <int NK, int NCB, int NP, int NIN, class Ring>
-NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, float* const (&dst)[NCB], int nvalid, int h, int c,
+template <int NK, int NCB, class M, int NIN, class Ring>
+NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][M::NP], int ks0, float* const (&dst)[NCB], int nvalid, int h, int c,
                             float inv_scale) {
     const char* wl = ring.consume();
     f16v acc[NCB];
@@ -340,7 +346,7 @@ NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, f
         return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile_p<M::PRODS, M::NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -356,8 +362,8 @@ NFL_DEV void dg_latent_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, f
 // an N-frequency encoding): chain the feature gradients through d/dx [x, w_k sin(2^k x), w_k cos(2^k x)]
 // into the gradient of the 3 encoded coordinates of this lane's sample (partial: the two lane halves
 // hold different rows and are summed by the caller).
-template <int N, int T, int NK, int NCB, int NP, int NIN, class Ring>
-NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, int h,
+template <int N, int T, int NK, int NCB, class M, int NIN, class Ring>
+NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][M::NP], int ks0, int h,
                         const float (&th)[NCB][3], const float (&tl)[NCB][3], const float* pw,
                         float (&g)[NCB][3]) {
     const char* wl = ring.consume();
@@ -367,7 +373,7 @@ NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, int h
         return in[ks0 + decltype(K)::value][cb][part];
     };
     NflNoEpi epi;
-    nfl_tile_p<DG_PRODS(NP), NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
+    nfl_tile_p<M::PRODS, M::NP, NCB, NK, 0, h8>(acc, wl, 0, getb, epi, ring);
     ring.template pieces<NK, Ring::MAXP>();
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
@@ -398,9 +404,10 @@ NFL_DEV void dg_pe_tile(Ring& ring, const h8 (&in)[NIN][NCB][NP], int ks0, int h
         }
 }
 
-template <int NFX, int NP>
+template <int NFX, int NP, int NWP>
 __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
-    using C = NflDgradCfg<NFX, NP>;
+    using M = DgMode<NP, NWP>;
+    using C = NflDgradCfg<NFX, M>;
     constexpr int NKP = C::NKP, WB = C::WBYTES, NCB = C::NCB;
     constexpr int GREC = NFL_GRD_SLOTS * NP;                   // slots of a segment's gradient record: hi (+ lo)
     constexpr int GLO = NP == 2 ? NFL_GRD_SLOTS * 1024 : 0;    // byte offset of the residual record
@@ -519,19 +526,19 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         h8 P[16][NCB][NP], Q[16][NCB][NP];
         K = nfl_dg_kargs();
         if (K->use_t) {
-            dg_tiles<WB, true, 4, 1, 1, 1, NCB, NP>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB, NP>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
+            dg_tiles<WB, true, 4, 1, 1, 1, NCB, M>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2));
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
             float* gt[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const size_t row = K->a.d_latent_row ? (size_t)K->a.d_latent_row[ray[cb]] : (size_t)ray[cb];     // table row or ray
                 gt[cb] = (K->a.d_g_t_emb && seg_ok[cb]) ? K->a.d_g_t_emb + row * 16 : nullptr;
             }
-            dg_latent_tile<8, NCB, NP>(ring, Q, 8, gt, 16, h, c, inv_scale);
+            dg_latent_tile<8, NCB, M>(ring, Q, 8, gt, 16, h, c, inv_scale);
         }
-        dg_tiles<WB, true, 4, 1, 0, 0, NCB, NP>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
+        dg_tiles<WB, true, 4, 1, 0, 0, NCB, M>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
         K = nfl_dg_kargs();
         if (K->has_a) {
             float* ga[NCB];
@@ -542,15 +549,15 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                 ga[cb] = (K->a.d_g_a_emb && seg_ok[cb]) ? K->a.d_g_a_emb + row * 48 : nullptr;
                 ga2[cb] = ga[cb] ? ga[cb] + 32 : nullptr;
             }
-            dg_latent_tile<8, NCB, NP>(ring, Q, 0, ga, 32, h, c, inv_scale);
-            dg_latent_tile<8, NCB, NP>(ring, Q, 0, ga2, 16, h, c, inv_scale);
+            dg_latent_tile<8, NCB, M>(ring, Q, 0, ga, 32, h, c, inv_scale);
+            dg_latent_tile<8, NCB, M>(ring, Q, 0, ga2, 16, h, c, inv_scale);
         }
         K = nfl_dg_kargs();
-        if (K->rays_tiles) dg_pe_tile<4, 0, 8, NCB, NP>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
+        if (K->rays_tiles) dg_pe_tile<4, 0, 8, NCB, M>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
         // d(h8) straight from the 128-wide head gradients: xyz_encoding_final is folded into W_dir' / W_t0' (nfl_plan.cpp),
         // so there are no d(feat) tiles; tile = [W_dir'^T: 8 k-steps | W_t0'^T: 8 (fields with a transient head) | W_sigma^T: 1]
         if (K->use_t) {
-            dg_tiles<WB, true, 8, 8, 8, 1, NCB, NP>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB, M>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
         } else if (K->has_t) {      // the stream carries the transient segment: multiply it by zeros
 #pragma unroll
             for (int ks = 8; ks < 16; ++ks)
@@ -561,27 +568,27 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                         Q[ks][cb][0][j] = (_Float16)0.f;
                         Q[ks][cb][NP - 1][j] = (_Float16)0.f;
                     }
-            dg_tiles<WB, true, 8, 8, 8, 1, NCB, NP>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB, M>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
         } else {
-            dg_tiles<WB, true, 8, 8, 1, 0, NCB, NP>(ring, moff, Q, 0, dS, 0, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 1, 0, NCB, M>(ring, moff, Q, 0, dS, 0, dS, 0, P, 0, gst, NFL_GRD_D(8));
         }
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(7));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(6));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(5));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(4));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(7));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(6));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(5));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(4));
         K = nfl_dg_kargs();
         if (K->rays_tiles) {       // skip connection: delta_5 (still in Q) reaches the encoded position too
-            dg_pe_tile<NFX, 0, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 0, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
         }
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(3));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(2));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, NP>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(1));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(3));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(2));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(1));
         if (K->rays_tiles) {
-            dg_pe_tile<NFX, 0, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            dg_pe_tile<NFX, 1, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
-            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB, NP>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 0, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            dg_pe_tile<NFX, 1, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
+            if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
             if (K->a.d_g_rays) {
                 // x = o + d z ; the view direction is d itself (no caller passes view_dir with learnable poses)
 #pragma unroll
@@ -614,10 +621,10 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
 #endif
 }
 
-template <int NFX, int NP>
+template <int NFX, int NP, int NWP>
 static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_packed, const nfl_dgrad_args* args,
                         hipStream_t stream) {
-    using C = NflDgradCfg<NFX, NP>;
+    using C = NflDgradCfg<NFX, DgMode<NP, NWP>>;
     constexpr int NCB_ = C::NCB;
     DgradArgs A;
     A.plan = static_cast<const NflPlan*>(d_plan);
@@ -645,12 +652,12 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     const int grid = (args->n_rays + rpw - 1) / rpw;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_dgrad_kernel<NFX, NP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_dgrad_kernel<NFX, NP, NWP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
             return NFL_ENODEV;
         attr_set = true;
     }
-    hipLaunchKernelGGL((nfl_dgrad_kernel<NFX, NP>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
+    hipLaunchKernelGGL((nfl_dgrad_kernel<NFX, NP, NWP>), dim3(grid), dim3(256), C::LDS_BYTES, stream, A);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }
 
@@ -662,13 +669,13 @@ extern "C" int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, con
     if (args->n_rays < 0 || args->n_samples < 1) return NFL_EINVAL;
     if (args->n_rays == 0) return NFL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hp->nsplit != 3) return NFL_EINVAL;      // both kernels read hi + lo weight fragments
-    if (hp->prec == NFL_PREC_F16X3) {          // three-product (fp32-class) backward: split gradients and stashes
-        if (hp->n_emb_xyz <= 10) return launch_dgrad<10, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
-        if (hp->n_emb_xyz <= 15) return launch_dgrad<15, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
-        return NFL_EINVAL;
-    }
-    if (hp->n_emb_xyz <= 10) return launch_dgrad<10, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
-    if (hp->n_emb_xyz <= 15) return launch_dgrad<15, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    const bool wide = hp->n_emb_xyz > 10;       // encoder widths: nfl_plan.h
+    if (hp->n_emb_xyz < 1 || hp->n_emb_xyz > NFL_MAX_EMB_XYZ) return NFL_EINVAL;
+    if (hp->prec == NFL_PREC_F16 && hp->nsplit == 1)
+        return wide ? launch_dgrad<15, 1, 1>(hp, d_bwd_plan, d_bwd_packed, args, s) : launch_dgrad<10, 1, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->prec == NFL_PREC_F16W && hp->nsplit == 3)
+        return wide ? launch_dgrad<15, 1, 2>(hp, d_bwd_plan, d_bwd_packed, args, s) : launch_dgrad<10, 1, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->prec == NFL_PREC_F16X3 && hp->nsplit == 3)
+        return wide ? launch_dgrad<15, 2, 2>(hp, d_bwd_plan, d_bwd_packed, args, s) : launch_dgrad<10, 2, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
     return NFL_EINVAL;
 }

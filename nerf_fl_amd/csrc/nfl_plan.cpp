@@ -117,13 +117,14 @@ static int check_desc(const nfl_field_desc* d) {
 // that holds the relu mask of that tile.
 extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, int bwd_prec, NflPlan* p) {
     if (!p || check_desc(d) != NFL_OK) return NFL_EINVAL;
-    if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
-    // hi + lo fp16 fragments of the transposed weights for BOTH backward arithmetics (the chain needs the weights to fp32
-    // class: nfl_dgrad.hip); gradients loss-scaled (nfl_loss_scale_from_bits).  One row tile per chunk (two 2 KiB-per-
-    // k-step tiles would not fit a ring slot).  `prec` records which kernel reads the stream.
-    common_init(d, NFL_PREC_F16X3, p);
+    if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16W && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
+    // fp16 fragments of the transposed weights, gradients loss-scaled (nfl_loss_scale_from_bits).  NFL_PREC_F16: hi
+    // fragments only (1 KiB per k-step), the 4- and 8-tile groups two tiles per ring chunk (one barrier per pair).
+    // NFL_PREC_F16W / NFL_PREC_F16X3: hi + lo fragments (2 KiB per k-step: the chain sees the weights to fp32 class), one
+    // tile per chunk (a pair would not fit a ring slot).  `prec` records which dgrad kernel reads the stream.
+    common_init(d, bwd_prec == NFL_PREC_F16 ? NFL_PREC_F16 : NFL_PREC_F16X3, p);
     p->prec = bwd_prec;
-    const bool pair = false;
+    const bool pair = bwd_prec == NFL_PREC_F16;
     p->elem = 0;
     p->is_bwd = 1;
     const int cx = 6 * d->n_emb_xyz + 3, cd = 6 * d->n_emb_dir + 3;

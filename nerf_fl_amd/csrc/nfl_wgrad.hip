@@ -571,7 +571,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     if ((grads->weight[NFL_P_DIR] || grads->weight[NFL_P_FINAL]) && !grads->bias[NFL_P_DIR]) return NFL_EINVAL;
     if (ut && (grads->weight[NFL_P_T0] || grads->weight[NFL_P_FINAL]) && !grads->bias[NFL_P_T0]) return NFL_EINVAL;
     if (n_rays < 0 || n_samples < 1) return NFL_EINVAL;
-    if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
+    if (bwd_prec != NFL_PREC_F16 && bwd_prec != NFL_PREC_F16W && bwd_prec != NFL_PREC_F16X3) return NFL_EINVAL;
     const int mult = bwd_prec == NFL_PREC_F16X3 ? 2 : 1;       // split stashes: [hi record | lo record] per segment
     WgArgs A;
     memset(&A, 0, sizeof(A));

@@ -36,6 +36,7 @@ from . import _lib
 __all__ = ["render_rays", "set_precision", "get_precision", "get_backward_precision", "check_status", "CameraRays"]
 
 _PREC = {"f16x3": _lib.NFL_PREC_F16X3, "f16": _lib.NFL_PREC_F16}
+_BPREC = dict(_PREC, f16w=_lib.NFL_PREC_F16W)
 _precision = os.environ.get("NERF_FL_AMD_PREC", "f16x3")
 _backward = os.environ.get("NERF_FL_AMD_BWD", "f16")
 
@@ -43,18 +44,23 @@ _backward = os.environ.get("NERF_FL_AMD_BWD", "f16")
 def set_precision(name=None, backward=None):
     """Forward arithmetic `name`: 'f16x3' (default; fp16 MFMA with split operands, 3 products, fp32-class accuracy) or
     'f16' (single product; fast, inference only).
-    `backward`: arithmetic of the MLP part of the hand-written backward (dgrad + wgrad): 'f16' (default: single fp16
-    products on fp16 stashes under a loss scale, gradients within a few 1e-3 of fp32 autograd) or 'f16x3' (split
-    operands hi+lo, 3 products, hi+lo activation / gradient stashes: the reference's fp32 precision class, at about twice
-    the backward's HBM traffic and three times its matrix work)."""
+    `backward`: arithmetic of the MLP part of the hand-written backward (dgrad + wgrad):
+      'f16'    (default) single fp16 products on fp16 stashes under a loss scale: gradients within a few 1e-3 of fp32
+               autograd per step, fastest.  The gradient chain multiplies by fp16-ROUNDED transposed weights, which leaves a
+               small systematic offset in long training curves (-0.4 .. -1 % of the late training loss on the NeRF-W parity
+               scene, validation PSNR unaffected: profiles/r03_psnr_backward_attribution.txt);
+      'f16w'   the same, but the chain reads hi + lo weight fragments (two products): the offset is gone, the training curve
+               lies within the reference's own run-to-run scatter; +9 % step time;
+      'f16x3'  split operands hi + lo everywhere, 3 products, hi + lo activation / gradient stashes: fp32-class gradients,
+               the reference's precision class, at about twice the backward's HBM traffic and three times its matrix work."""
     global _precision, _backward
     if name is not None:
         if name not in _PREC:
             raise ValueError(f"precision must be one of {sorted(_PREC)}")
         _precision = name
     if backward is not None:
-        if backward not in ("f16", "f16x3"):
-            raise ValueError("backward must be 'f16' or 'f16x3'")
+        if backward not in _BPREC:
+            raise ValueError(f"backward must be one of {sorted(_BPREC)}")
         _backward = backward
 
 
@@ -234,7 +240,7 @@ class _PackedField:
         """Plan + buffer of the dgrad stream (transposed weights, fp16 -- hi + lo fragments for the three-product backward);
         packed by ensure_bwd_packed / _pack_streams."""
         L = _lib.lib()
-        bprec = _PREC[_backward] if bprec is None else bprec
+        bprec = _BPREC[_backward] if bprec is None else bprec
         rg = (int(bool(rays_grad)), bprec)
         if rg not in self.bplans:
             nbytes = L.nfl_plan_bytes(C.byref(self.desc))
@@ -736,7 +742,7 @@ def render_rays(models, embeddings, rays, ts, N_samples=64, use_disp=False, pert
                    white_back=bool(white_back), test_time=test_time, raw=bool(kwargs.get("_field_raw", False)),
                    view_dir=None, perturb_rand=None, noise_c=None, noise_f=None, u=None, u_row=None,
                    use_t=False, f_f=None, rays_grad=rays_grad, pe_w_xyz=None, pe_w_dir=None, z_fine=None, loss=None,
-                   latent_tables=False, ts=None, arena=kwargs.get("grad_arena"), bprec=_PREC[_backward])
+                   latent_tables=False, ts=None, arena=kwargs.get("grad_arena"), bprec=_BPREC[_backward])
         if kwargs.get("loss_target") is not None:
             # build-defined: NerfWLoss (losses.py:35-50) fused into the per-ray epilogue of the training passes.  The result
             # gains `_nerfw_loss` (scalar, the only output that carries gradient then) and `_nerfw_terms` (4,)

@@ -74,25 +74,28 @@ def test_bwd_plan_structure(L):
     buf = C.create_string_buffer(n)
     assert L.nfl_bwd_plan_build(C.byref(d), 0, _lib.NFL_PREC_F16, buf, n) == 0
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
-    # dgrad stream of the default backward: hi + lo fp16 fragments of the transposed weights (nsplit 3: the chain needs the
-    # weights to fp32 class), read by the two-product kernel (prec = NFL_PREC_F16), no rays-gradient tiles
-    assert hdr[1] == 1 and hdr[2] == 3 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == (4 << 8)      # flags: no rays tiles | n_emb_dir << 8
+    # dgrad stream of the default backward (prec = NFL_PREC_F16): hi fragments only, no rays-gradient tiles
+    assert hdr[1] == 1 and hdr[2] == 1 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == (4 << 8)      # flags: no rays tiles | n_emb_dir << 8
     n_rt, n_chunks, total_ks = hdr[12], hdr[15], hdr[18]
-    # transposed row tiles: transient 4+12+1, rgb^T 4, appearance rows 2, h8 8 (dir' | t0' | sigma), 7 trunk layers x 8; one tile per chunk
+    # transposed row tiles: transient 4+12+1, rgb^T 4, appearance rows 2, h8 8 (dir' | t0' | sigma), 7 trunk layers x 8; the tiles of
+    # the 4- and 8-tile groups travel two per chunk, the latent rows one per chunk
     assert n_rt == 17 + 4 + 2 + 8 + 56
-    assert n_chunks == n_rt
-    assert hdr[16] == 17                                    # first chunk of the non-transient part (n_chunks_sigma re-used)
+    assert n_chunks == (2 + 6 + 1) + 2 + 2 + 4 + 28
+    assert hdr[16] == 9                                     # first chunk of the non-transient part (n_chunks_sigma re-used)
     assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 17 + 56 * 16
-    assert L.nfl_bwd_packed_bytes(C.byref(d), 0, _lib.NFL_PREC_F16) == total_ks * 2048 + n_rt * 128
+    assert L.nfl_bwd_packed_bytes(C.byref(d), 0, _lib.NFL_PREC_F16) == total_ks * 1024 + n_rt * 128
     # with the gradient w.r.t. the rays: + direction rows (1 tile, 8 ks) + encoded-position rows of layers 5 and 1 (2 x 2 tiles, 16 ks)
     assert L.nfl_bwd_plan_build(C.byref(d), 1, _lib.NFL_PREC_F16, buf, n) == 0
     hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)
     assert hdr2[5] == (1 | 4 << 8) and hdr2[12] == n_rt + 5 and hdr2[15] == n_chunks + 5 and hdr2[18] == total_ks + 8 + 4 * 16
-    # the three-product (fp32-class) backward reads the same stream (prec tells the kernels apart)
-    assert L.nfl_bwd_plan_build(C.byref(d), 0, _lib.NFL_PREC_F16X3, buf, n) == 0
-    hdr3 = np.frombuffer(buf.raw[:96], dtype=np.int32)
-    assert hdr3[1] == 0 and hdr3[2] == 3 and hdr3[4] == 1 and hdr3[12] == n_rt and hdr3[15] == n_rt and hdr3[18] == total_ks
-    assert L.nfl_bwd_packed_bytes(C.byref(d), 0, _lib.NFL_PREC_F16X3) == total_ks * 2048 + n_rt * 128
+    # exact-weight chain (F16W) and three-product backward (F16X3): the same tiles as hi + lo fragments (2 KiB per k-step),
+    # one tile per chunk; `prec` tells the dgrad kernels apart
+    for bp in (_lib.NFL_PREC_F16W, _lib.NFL_PREC_F16X3):
+        assert L.nfl_bwd_plan_build(C.byref(d), 0, bp, buf, n) == 0
+        hdr3 = np.frombuffer(buf.raw[:96], dtype=np.int32)
+        assert hdr3[1] == bp and hdr3[2] == 3 and hdr3[4] == 1 and hdr3[12] == n_rt and hdr3[15] == n_rt and hdr3[18] == total_ks
+        assert hdr3[16] == 17                               # transient part: 17 tiles = 17 chunks
+        assert L.nfl_bwd_packed_bytes(C.byref(d), 0, bp) == total_ks * 2048 + n_rt * 128
     assert L.nfl_bwd_plan_build(C.byref(d), 0, 7, buf, n) == -1
     # stash sizes: per 32-sample segment 178 / 173 KiB (no slot for xyz_encoding_final's output or its gradient: composed) (+ 4 KiB tail pad), then 84 relu-mask words x 256 B per segment
     assert L.nfl_act_stash_bytes(C.byref(d), 8, 128, _lib.NFL_PREC_F16) == 8 * 4 * 178 * 1024 + 4096 + 8 * 4 * 84 * 256
@@ -100,6 +103,8 @@ def test_bwd_plan_structure(L):
     # split (hi + lo) records for the three-product backward: twice the record, the same mask words
     assert L.nfl_act_stash_bytes(C.byref(d), 8, 128, _lib.NFL_PREC_F16X3) == 8 * 4 * 2 * 178 * 1024 + 4096 + 8 * 4 * 84 * 256
     assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100, _lib.NFL_PREC_F16X3) == (8 * 4 + 1) * 2 * 173 * 1024 + 4096
+    assert L.nfl_act_stash_bytes(C.byref(d), 8, 128, _lib.NFL_PREC_F16W) == L.nfl_act_stash_bytes(C.byref(d), 8, 128, _lib.NFL_PREC_F16)
+    assert L.nfl_grad_stash_bytes(C.byref(d), 8, 100, _lib.NFL_PREC_F16W) == L.nfl_grad_stash_bytes(C.byref(d), 8, 100, _lib.NFL_PREC_F16)
 
 
 def test_encoder_widths(L):

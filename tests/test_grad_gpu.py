@@ -179,12 +179,14 @@ def compare(cfg, a, got):
             yield "proj", key, abs(float((g.flatten().double() * pr.double()).sum()) - exp.item()) / a["gradnorm." + key[9:]].item()
 
 
-@pytest.mark.parametrize("backward", ["f16", "f16x3"])
+@pytest.mark.parametrize("backward", ["f16", "f16w", "f16x3"])
 @pytest.mark.parametrize("name", CASES)
 def test_gradients_vs_reference(name, backward):
     cfg, a, got, loss = run_case(name, backward)
     assert abs(loss - a["loss"].item()) <= 1e-4 * max(1.0, abs(a["loss"].item()))
-    table = THRESH if backward == "f16" else (THRESH_X3_TRAINED if name.startswith("g17_") else THRESH_X3)
+    # f16w (the chain reads hi + lo weight fragments) keeps f16's stashes and single-product weight gradients: per-step
+    # errors of the same class, held to the same thresholds
+    table = THRESH if backward != "f16x3" else (THRESH_X3_TRAINED if name.startswith("g17_") else THRESH_X3)
     bad, seen = {}, {m: 0 for m in THRESH}
     for measure, key, val in compare(cfg, a, got):
         seen[measure] += 1

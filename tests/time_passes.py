@@ -21,7 +21,7 @@ m = m.to(dev)
 f = rnd._field(m, 10, 4, dev)
 BWD = sys.argv[sys.argv.index("--backward") + 1] if "--backward" in sys.argv else "f16"      # f16 | f16x3
 nerf_fl_amd.set_precision(backward=BWD)
-BP = rnd._PREC[BWD]
+BP = rnd._BPREC[BWD]
 bp = f.ensure_bwd_packed(False, BP)
 rays = orc.make_rays(R, 100).to(dev)
 z = torch.sort(2 + 4 * torch.rand(R, F, device=dev), dim=1)[0]
