@@ -76,6 +76,9 @@ def parse_args(argv=None):
     ap.add_argument("--sustained-seconds", type=float, default=2.0,
                     help="after the timed steps: keep stepping for this long with one HIP-event pair per step and report "
                          "median / p90 (`sustained`); 0 = off")
+    ap.add_argument("--only-default-backward", action="store_true",
+                    help="skip the companion measurements of the other backward arithmetics (the rocprofv3 --stats pass of "
+                         "profiles/collect.sh: keeps one population per kernel in the trace)")
     ap.add_argument("--backward", default="f16", choices=["f16", "f16w", "f16x3"],
                     help="arithmetic of the MLP backward: f16 = single fp16 product (default), f16w = the gradient chain reads "
                          "hi+lo weight fragments (two products: no systematic training-curve offset), f16x3 = split operands, "
@@ -339,7 +342,8 @@ def run_rank(args):
     #   f16x3: operands split everywhere, three products, split stashes -- the train-step figure at the reference's
     #          precision class (`value_fp32_class`)
     other_modes = {}
-    if args.mode == "train" and args.precision == "f16x3" and args.backward == "f16" and not args.no_extras:
+    if (args.mode == "train" and args.precision == "f16x3" and args.backward == "f16" and not args.no_extras
+            and not args.only_default_backward):
         descr = {"f16w": "as the default (fp16 MFMA, 1 product, fp16 stashes, loss scale) but the gradient chain W^T delta reads "
                          "hi+lo weight fragments (2 products): weights to fp32 class in the chain",
                  "f16x3": "fp16 MFMA, weights / activations / gradients split hi+lo, 3 products, fp32 accumulate; "
