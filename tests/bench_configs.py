@@ -74,6 +74,11 @@ c2w = make_c2w(torch.tensor([0.0, 0.05, 0.0]), torch.tensor([0.0, 0.0, 4.0]))[:3
 kw = dict(chunk=chunk, white_back=False, device=dev, output_transient=False)
 dt = timed(lambda: render_frame(models, emb, c2w, K, H, W, 0.3, 5.0, 128, 128, ts=7, **kw), 3, 1)
 out["cfg5_frame_800x800_camera_prologue"] = {"ms_per_frame": dt * 1e3, "rays_per_s": H * W / dt}
+# the same with the chunk replayed from ONE HIP graph whose prologue reads the camera from device memory (configs[4]:
+# "hipGraph-captured eval.py inference" + the camera prologue, combined since round 3: nfl_pass_args::d_cam)
+gcache = {}
+dt = timed(lambda: render_frame(models, emb, c2w, K, H, W, 0.3, 5.0, 128, 128, ts=7, use_graph=True, _graph_cache=gcache, **kw), 3, 1)
+out["cfg5_frame_800x800_camera_prologue_hip_graph"] = {"ms_per_frame": dt * 1e3, "rays_per_s": H * W / dt, "captures": len(gcache)}
 ts_f = torch.full((H * W,), 7, dtype=torch.long, device=dev)
 dt = timed(lambda: batched_inference(models, emb, frame_rays(c2w, K, H, W, 0.3, 5.0, dev), ts_f, 128, 128, chunk=chunk,
                                      white_back=False, output_transient=False), 3, 1)

@@ -56,3 +56,18 @@ def test_two_ranks_drive_the_real_render_path():
     assert out["n_gpus"] == 2 and out["ranks"] == 2
     assert out["replica_param_max_diff"] == 0.0
     assert out["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_graphed_step_keeps_replicas_identical():
+    """The same rehearsal with the step replayed from HIP graphs: with gloo the collective cannot be captured,
+    so the step is two graphs around an eager in-place all-reduce of the gradient arena; after the replays the two replicas'
+    parameters must still be bit-identical."""
+    p = _run(["--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--graph", "--sustained-seconds", "0"],
+             {"NFL_BENCH_BACKEND": "gloo", "NFL_BENCH_ONE_DEVICE": "1"}, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["hip_graph"] is True and out["backend"] == "gloo"
+    assert out["all_reduce"]["captured_in_graph"] is False
+    assert out["replica_param_max_diff"] == 0.0
+    assert out["value"] > 0
