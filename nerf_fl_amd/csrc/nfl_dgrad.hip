@@ -661,6 +661,23 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }
 
+// Compiled twice (Makefile): NFL_DGRAD_WIDE=0 -> nfl_dgrad.o, the C entry point and the kernels for up to 10 frequencies;
+// NFL_DGRAD_WIDE=1 -> nfl_dgrad_w.o, the kernels for 11..15 -- the two halves compile in parallel.
+#ifndef NFL_DGRAD_WIDE
+#define NFL_DGRAD_WIDE 0
+#endif
+#if NFL_DGRAD_WIDE
+extern "C" int nfl_mlp_dgrad_wide(const NflPlan* hp, const void* d_bwd_plan, const void* d_bwd_packed, const nfl_dgrad_args* args,
+                                  void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hp->prec == NFL_PREC_F16 && hp->nsplit == 1) return launch_dgrad<15, 1, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->prec == NFL_PREC_F16W && hp->nsplit == 3) return launch_dgrad<15, 1, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->prec == NFL_PREC_F16X3 && hp->nsplit == 3) return launch_dgrad<15, 2, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    return NFL_EINVAL;
+}
+#else
+extern "C" int nfl_mlp_dgrad_wide(const NflPlan*, const void*, const void*, const nfl_dgrad_args*, void*);
+
 extern "C" int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
                              const nfl_dgrad_args* args, void* stream) {
     const NflPlan* hp = static_cast<const NflPlan*>(h_bwd_plan);
@@ -669,13 +686,11 @@ extern "C" int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, con
     if (args->n_rays < 0 || args->n_samples < 1) return NFL_EINVAL;
     if (args->n_rays == 0) return NFL_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool wide = hp->n_emb_xyz > 10;       // encoder widths: nfl_plan.h
     if (hp->n_emb_xyz < 1 || hp->n_emb_xyz > NFL_MAX_EMB_XYZ) return NFL_EINVAL;
-    if (hp->prec == NFL_PREC_F16 && hp->nsplit == 1)
-        return wide ? launch_dgrad<15, 1, 1>(hp, d_bwd_plan, d_bwd_packed, args, s) : launch_dgrad<10, 1, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
-    if (hp->prec == NFL_PREC_F16W && hp->nsplit == 3)
-        return wide ? launch_dgrad<15, 1, 2>(hp, d_bwd_plan, d_bwd_packed, args, s) : launch_dgrad<10, 1, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
-    if (hp->prec == NFL_PREC_F16X3 && hp->nsplit == 3)
-        return wide ? launch_dgrad<15, 2, 2>(hp, d_bwd_plan, d_bwd_packed, args, s) : launch_dgrad<10, 2, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->n_emb_xyz > 10) return nfl_mlp_dgrad_wide(hp, d_bwd_plan, d_bwd_packed, args, stream);      // encoder widths: nfl_plan.h
+    if (hp->prec == NFL_PREC_F16 && hp->nsplit == 1) return launch_dgrad<10, 1, 1>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->prec == NFL_PREC_F16W && hp->nsplit == 3) return launch_dgrad<10, 1, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
+    if (hp->prec == NFL_PREC_F16X3 && hp->nsplit == 3) return launch_dgrad<10, 2, 2>(hp, d_bwd_plan, d_bwd_packed, args, s);
     return NFL_EINVAL;
 }
+#endif
