@@ -74,7 +74,8 @@ struct WgArgs {
     const char* grd;     // gradient stash
     int n_seg;
     int act_rec, grd_rec;            // slots per segment record of the two stashes (twice the plan's with split stashes)
-    int bias_on;                     // 0: this launch adds nothing to the bias gradients (third product of a split backward)
+    int act_lo, grd_lo;              // split stashes: byte offset of the residual record behind the hi record (0: none)
+    int slot_bytes;                  // bytes of one LDS slot of this launch (all hi (+ lo) pieces of the largest job)
     int wg_start[WG_MAX_JOBS + 1];   // workgroups [wg_start[j], wg_start[j+1]) work on job j
     nfl_field_grads g;
     float* scratch;      // (256, 256): rows 0..127 G (delta_dirh (x) h8), rows 128..255 Gt (delta_g1 (x) h8)
@@ -143,7 +144,7 @@ __device__ __forceinline__ void wg_flush(const WgArgs& A, const WgJob& J, f16v (
                 }
             }
         });
-        if (J.do_bias && A.bias_on && wi == 0 && layer != WG_SCRATCH && A.g.bias[layer] != nullptr) {
+        if (J.do_bias && wi == 0 && layer != WG_SCRATCH && A.g.bias[layer] != nullptr) {
             const float tot = bsum[a] + __shfl_xor(bsum[a], 32);
             const int oi = wg_orig(TO.kind, n);
             if (hh == 0 && oi < TO.nvalid) atomicAdd(A.g.bias[layer] + TO.idx0 + oi, tot);
@@ -152,23 +153,34 @@ __device__ __forceinline__ void wg_flush(const WgArgs& A, const WgJob& J, f16v (
 }
 
 typedef unsigned wg_u4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void wg_gload(wg_u4& dst, const char* ptr) {
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(ptr));
+// scalar base (the segment's record, uniform) + 32-bit per-lane offset: one VGPR of address per piece instead of two
+__device__ __forceinline__ void wg_gload(wg_u4& dst, unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase));
 }
 // wait until at most N vector-memory operations are outstanding; the register set rides through so its users stay below
 template <int N, int PW>
 __device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
     static_assert(N < 64, "vmcnt is a 6-bit counter");
-    static_assert(PW == 4 || PW == 5 || PW == 6 || PW == 8, "piece counts the dispatcher uses");
+    static_assert(PW == 4 || PW == 5 || PW == 6 || PW == 8 || PW == 10 || PW == 12 || PW == 16, "piece counts the dispatcher uses");
     if constexpr (PW == 4)
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
     else if constexpr (PW == 5)
         asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(N));
     else if constexpr (PW == 6)
         asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]) : "n"(N));
-    else
+    else if constexpr (PW == 8)
         asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
                      "+v"(r[6]), "+v"(r[7]) : "n"(N));
+    else if constexpr (PW == 10)
+        asm volatile("s_waitcnt vmcnt(%10)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
+                     "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]) : "n"(N));
+    else if constexpr (PW == 12)
+        asm volatile("s_waitcnt vmcnt(%12)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
+                     "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]) : "n"(N));
+    else
+        asm volatile("s_waitcnt vmcnt(%16)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
+                     "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]),
+                     "+v"(r[14]), "+v"(r[15]) : "n"(N));
 }
 
 // The stream is staged through REGISTERS.  An LDS-DMA ring (the first design: 4 slots of 32-40 KiB, 1.43 ms per
@@ -179,28 +191,36 @@ __device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
 // ds_write_b128 when its turn comes, and re-issues loads into the freed registers at once: 1.13 ms = 5.7 TB/s.
 // One barrier per segment; no branch inside a segment: a wave whose share is short works on a clamped
 // (duplicate) tile and drops it at the flush.
-template <int PW, int NITW, int D>
+// SPLIT (three-product weight gradient, NFL_PREC_F16X3): the residual images of every tile travel with the hi images (twice
+// the pieces per segment, the lo pieces behind the hi pieces in the LDS slot) and every accumulator gets
+// d_hi (x) h_hi + d_lo (x) h_hi + d_hi (x) h_lo -- one pass over hi + lo instead of three passes of the one-product GEMM.
+template <int PW, int NITW, int D, bool SPLIT = false>
 __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, const int act_slots, const int grd_slots,
                                            const int seg0, const int seg1, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave % J.n_wo, wi = wave / J.n_wo;
-    const int n_pieces = 2 * (J.n_ot + J.n_it);
+    const int n_hi = 2 * (J.n_ot + J.n_it);
+    const int n_pieces = SPLIT ? 2 * n_hi : n_hi;
 
-    const char* psrc[PW];
-    size_t pstride[PW];
+    unsigned poff[PW];          // byte offset of this lane's 16 B of the piece inside its segment record
+    unsigned outmask = 0u;      // bit pp: piece pp comes from the gradient stash (else: activation stash)
     int pdst[PW];
 #pragma unroll
     for (int pp = 0; pp < PW; ++pp) {
         int p = wave + 4 * pp;
         p = p < n_pieces ? p : n_pieces - 1;
-        const int t = p >> 1;
+        const bool lo = p >= n_hi;
+        const int q = lo ? p - n_hi : p;
+        const int t = q >> 1;
         const bool is_out = t < J.n_ot;
-        const int slot = (is_out ? J.ot[t].slot : J.it[t - J.n_ot].slot) + (p & 1);
-        psrc[pp] = (is_out ? A.grd : A.act) + (size_t)slot * 1024 + lane * 16;
-        pstride[pp] = (size_t)(is_out ? grd_slots : act_slots) * 1024;
+        const int slot = (is_out ? J.ot[t].slot : J.it[t - J.n_ot].slot) + (q & 1);
+        poff[pp] = (unsigned)slot * 1024u + lane * 16u + (lo ? (unsigned)(is_out ? A.grd_lo : A.act_lo) : 0u);
+        outmask |= is_out ? (1u << pp) : 0u;
         pdst[pp] = p * WG_PSTRIDE + lane * 16;
     }
+    outmask = __builtin_amdgcn_readfirstlane(outmask);
+    const size_t grd_stride = (size_t)grd_slots * 1024, act_stride = (size_t)act_slots * 1024;
     // The loads and their waits are hand-issued: left to hipcc the loop header gets an s_waitcnt vmcnt(0), which
     // drains all D segments once per trip.  VMEM operations return in order, so "all but the (D-1)*PW youngest"
     // is exactly "the oldest register set has landed"; nothing else in the loop touches vector memory.
@@ -208,8 +228,10 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
     auto gload = [&](int seg, auto DD) __attribute__((always_inline)) {
         constexpr int d = decltype(DD)::value;
         const int sg = seg < seg1 ? seg : seg1 - 1;          // surplus loads re-read the last segment
+        const char* bo = A.grd + (size_t)sg * grd_stride;
+        const char* bi = A.act + (size_t)sg * act_stride;
 #pragma unroll
-        for (int pp = 0; pp < PW; ++pp) wg_gload(R[d][pp], psrc[pp] + (size_t)sg * pstride[pp]);
+        for (int pp = 0; pp < PW; ++pp) wg_gload(R[d][pp], poff[pp], ((outmask >> pp) & 1u) ? bo : bi);
     };
 
     int my_ot[WG_NOT], my_it[NITW];
@@ -240,7 +262,7 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
             constexpr int d = decltype(DD)::value;
             const int seg = base + d;
             if (seg < seg1) {                                     // uniform
-                char* slot = smem + ((seg - seg0) & 1) * WG_SLOT;
+                char* slot = smem + ((seg - seg0) & 1) * A.slot_bytes;
                 wg_landed<(D - 1) * PW, PW>(R[d]);
 #pragma unroll
                 for (int pp = 0; pp < PW; ++pp) *reinterpret_cast<wg_u4*>(slot + pdst[pp]) = R[d][pp];
@@ -271,6 +293,30 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
 #pragma unroll
                         for (int a = 0; a < WG_NOT; ++a)
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    if constexpr (SPLIT) {
+                        const char* base_lo = base_l + n_hi * WG_PSTRIDE;        // the lo pieces follow the hi pieces
+                        h8 al[WG_NOT];
+#pragma unroll
+                        for (int a = 0; a < WG_NOT; ++a) {
+                            al[a] = wg_operand(base_lo + ot_off[a], lane, m);
+                            float sacc = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) sacc += (float)al[a][j];
+                            bsum[a] += sacc;                              // db = sum_s (d_hi + d_lo)
+                        }
+#pragma unroll
+                        for (int b = 0; b < NITW; ++b)
+#pragma unroll
+                            for (int a = 0; a < WG_NOT; ++a)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bv[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < NITW; ++b) {
+                            const h8 bl = wg_operand(base_lo + it_off[b], lane, m);
+#pragma unroll
+                            for (int a = 0; a < WG_NOT; ++a)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[a], bl, acc[a][b], 0, 0, 0);
+                        }
+                    }
                 }
             }
         });
@@ -279,6 +325,7 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
     wg_flush<NITW>(A, J, acc, bsum, wo, wi, lane);
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WgPlan& P = *A.plan;
@@ -291,6 +338,21 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     const WgJob& J = P.job[j];
     const int pw = P.cost[j];
     const int nitw = (J.n_it + J.n_wi - 1) / J.n_wi;       // in tiles per wave
+    if constexpr (SPLIT) {      // twice the pieces per segment in flight per set: fewer sets (the registers are the same)
+        if (pw <= 4) {
+            if (nitw <= 1) wg_body_rs<8, 1, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+            else wg_body_rs<8, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        } else if (pw <= 5) {
+            wg_body_rs<10, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        } else if (pw <= 6) {
+            wg_body_rs<12, 4, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        } else {
+            if (nitw <= 5) wg_body_rs<16, 5, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+            else if (nitw <= 6) wg_body_rs<16, 6, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+            else wg_body_rs<16, 8, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        }
+        return;
+    }
     if (pw <= 4) {
         if (nitw <= 1) wg_body_rs<4, 1, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
         else wg_body_rs<4, 2, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
@@ -580,7 +642,12 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     A.grd = d_grad_stash;
     A.act_rec = hp->act_slots * mult;
     A.grd_rec = hp->grd_slots * mult;
-    A.bias_on = 1;
+    A.act_lo = mult == 2 ? hp->act_slots * 1024 : 0;
+    A.grd_lo = mult == 2 ? hp->grd_slots * 1024 : 0;
+    int max_tiles = 1;
+    for (int j = 0; j < hp->n_jobs; ++j)
+        if (hp->job[j].n_ot + hp->job[j].n_it > max_tiles) max_tiles = hp->job[j].n_ot + hp->job[j].n_it;
+    A.slot_bytes = WG_TSTRIDE * max_tiles * mult;
     A.n_seg = n_rays * ((n_samples + 31) / 32);
     A.g = *grads;
     A.scratch = d_scratch;
@@ -618,11 +685,14 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     A.wg_start[nj] = acc_wg;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_SLOT) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WG_SLOT) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 4 * WG_SLOT) != hipSuccess)
             return NFL_ENODEV;
         attr_set = true;
     }
+    if (2 * A.slot_bytes > 4 * WG_SLOT) return NFL_EINVAL;
     WgTensors T;
     for (int L = 0; L < NFL_NUM_LAYERS; ++L) {
         T.ptr[L] = grads->weight[L];
@@ -635,25 +705,25 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 0, d_gmax);
     if (n_rays == 0) return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
-    hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, A);
 #ifdef NFL_DIAG_WGRAD_PASSES
-    const int wg_passes = NFL_DIAG_WGRAD_PASSES;
-#else
-    const int wg_passes = 3;
-#endif
-    if (mult == 2) {
-        // three-product weight gradient, dW = sum_s (d_hi + d_lo) (x) (h_hi + h_lo) without the lo x lo term: the same
-        // streaming GEMM over the residual records, accumulated into the same fp32 tensors (fp16 x fp16 products are exact
-        // in the fp32 accumulators, so what is left is the 2^-22 lo x lo term and the summation order).  The bias gradients
-        // are sum_s (d_hi + d_lo): the second launch adds its share, the third (h_lo) none.
+    // diagnostic (nfl_diag.h): the split stashes read by the ONE-product GEMM, hi images only (1) or d_hi + d_lo (2)
+    {
         WgArgs B = A;
-        B.grd = d_grad_stash + (size_t)hp->grd_slots * 1024;
-        if (wg_passes >= 2) hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
-        B = A;
-        B.act = d_act_stash + (size_t)hp->act_slots * 1024;
-        B.bias_on = 0;
-        if (wg_passes >= 3) hipLaunchKernelGGL(nfl_wgrad_kernel, dim3(acc_wg), dim3(256), 2 * WG_SLOT, s, B);
+        B.act_lo = B.grd_lo = 0;
+        B.slot_bytes = A.slot_bytes / mult;
+        hipLaunchKernelGGL(nfl_wgrad_kernel<false>, dim3(acc_wg), dim3(256), 2 * B.slot_bytes, s, B);
+        if (mult == 2 && NFL_DIAG_WGRAD_PASSES >= 2) {
+            B.grd = d_grad_stash + (size_t)hp->grd_slots * 1024;
+            hipLaunchKernelGGL(nfl_wgrad_kernel<false>, dim3(acc_wg), dim3(256), 2 * B.slot_bytes, s, B);
+        }
     }
+#else
+    // NFL_PREC_F16X3: dW = sum_s (d_hi + d_lo) (x) (h_hi + h_lo) without the lo x lo term, in ONE pass over the hi and lo
+    // records (fp16 x fp16 products are exact in the fp32 accumulators, so what is left is the 2^-22 lo x lo term and the
+    // summation order); the bias gradients are sum_s (d_hi + d_lo).
+    if (mult == 2) hipLaunchKernelGGL(nfl_wgrad_kernel<true>, dim3(acc_wg), dim3(256), 2 * A.slot_bytes, s, A);
+    else hipLaunchKernelGGL(nfl_wgrad_kernel<false>, dim3(acc_wg), dim3(256), 2 * A.slot_bytes, s, A);
+#endif
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 1, d_gmax);
 
     // the composition through xyz_encoding_final (file header); G, db_dir, db_t0 are final (unscaled) by now

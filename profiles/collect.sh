@@ -25,4 +25,8 @@ python3 tests/bench_configs.py > "$OUT/bench_configs.json" 2> "$OUT/bench_config
 python3 bench.py --no-extras --workload cfg3 --rays 4096 --steps 20 --warmup 5 > "$OUT/bench_cfg3_r4096.json" 2>/dev/null
 python3 bench.py --no-extras --workload cfg3 --rays 1024 --steps 100 --warmup 10 --graph > "$OUT/bench_cfg3_r1024_graph.json" 2>/dev/null
 python3 bench.py --no-extras --workload cfg3 --rays 1024 --steps 100 --warmup 10 > "$OUT/bench_cfg3_r1024.json" 2>/dev/null
-find "$OUT" -name "*.csv" | head -20
+# reduce here (the raw output is more than gpurun copies back) and keep only the reduction
+python3 profiles/make_summary.py "$OUT" "$TAG" "$ROOT/gpurun_out/${TAG}_reduced"
+cp "$OUT"/*.log "$OUT"/*.err "$ROOT/gpurun_out/${TAG}_reduced/" 2>/dev/null || true
+if [ -z "$NFL_KEEP_RAW" ]; then rm -rf "$OUT"; fi
+ls "$ROOT/gpurun_out/${TAG}_reduced"

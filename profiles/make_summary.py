@@ -15,7 +15,11 @@ import shutil
 import sys
 
 src, tag = sys.argv[1], sys.argv[2]
-here = os.path.dirname(os.path.abspath(__file__))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# third argument: where to write (default: profiles/).  profiles/collect.sh reduces on the GPU box into gpurun_out/<tag>_reduced,
+# because the raw rocprofv3 output (~80 MB) is more than gpurun copies back; the reduced files are then copied here.
+here = sys.argv[3] if len(sys.argv) > 3 else os.path.dirname(os.path.abspath(__file__))
+os.makedirs(here, exist_ok=True)
 
 
 def one(pattern):
@@ -118,7 +122,7 @@ step_traffic = {"hbm_bytes": (2.0 * tot_f + tot_w) * 1024.0 / n_steps, "steps_co
                         "backward (DESIGN.md section 5)"}
 import datetime
 import hashlib
-lib = os.path.join(os.path.dirname(here), "nerf_fl_amd", "libnerf_fl_amd.so")
+lib = os.path.join(root, "nerf_fl_amd", "libnerf_fl_amd.so")
 provenance = {"tag": tag, "collected_utc": datetime.datetime.utcnow().strftime("%Y-%m-%dT%H:%MZ"),
               "lib_sha16": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16] if os.path.exists(lib) else None,
               "command": "profiles/collect.sh " + tag}

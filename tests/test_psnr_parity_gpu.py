@@ -163,8 +163,20 @@ def reference_runs(kind):
     return [np.load(f, allow_pickle=False) for f in files]
 
 
+def _n_ref(kind):
+    import glob
+    import os
+
+    import golden_util as gu
+    return len(glob.glob(os.path.join(gu.GOLDEN_DIR, f"psnr_{kind}.npz")) + glob.glob(os.path.join(gu.GOLDEN_DIR, f"psnr_{kind}_replica*.npz")))
+
+
+# "smooth": the sharper scene (the same sphere without stripes, 512 rays per step, 800 steps: the reference reaches
+# 26.7 dB instead of 22) -- so that the comparison is not made at one quality level only
 @pytest.mark.parametrize("kind,backward", [("base", "f16"), ("nerfw", "f16"), ("nerfw", "f16w"), ("nerfw", "f16x3"),
-                                           ("base", "f16w")])
+                                           ("base", "f16w"),
+                                           pytest.param("smooth", "f16", marks=pytest.mark.skipif(
+                                               _n_ref("smooth") < 6, reason="fewer than 6 stored reference runs of the smooth scene"))])
 def test_fit_psnr_matches_reference_64_64(kind, backward):
     import json
 
@@ -173,7 +185,7 @@ def test_fit_psnr_matches_reference_64_64(kind, backward):
     import nerf_fl_amd
     import psnr_scene as sc
     refs = reference_runs(kind)
-    assert len(refs) >= 10
+    assert len(refs) >= (6 if kind == "smooth" else 10)
     for r in refs:
         assert json.loads(str(r["cfg"])) == sc.CONFIGS[kind], "a stored reference run was made with other hyper-parameters"
     steps, win = sc.CONFIGS[kind]["steps"], 50
