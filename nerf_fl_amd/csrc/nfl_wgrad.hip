@@ -161,7 +161,7 @@ __device__ __forceinline__ void wg_gload(wg_u4& dst, unsigned voff, const char* 
 template <int N, int PW>
 __device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
     static_assert(N < 64, "vmcnt is a 6-bit counter");
-    static_assert(PW == 4 || PW == 5 || PW == 6 || PW == 8 || PW == 10 || PW == 12 || PW == 16, "piece counts the dispatcher uses");
+    static_assert(PW == 4 || PW == 5 || PW == 6 || PW == 8 || PW == 12 || PW == 16, "piece counts the dispatcher uses");
     if constexpr (PW == 4)
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
     else if constexpr (PW == 5)
@@ -171,9 +171,6 @@ __device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
     else if constexpr (PW == 8)
         asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
                      "+v"(r[6]), "+v"(r[7]) : "n"(N));
-    else if constexpr (PW == 10)
-        asm volatile("s_waitcnt vmcnt(%10)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
-                     "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]) : "n"(N));
     else if constexpr (PW == 12)
         asm volatile("s_waitcnt vmcnt(%12)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]),
                      "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]) : "n"(N));
@@ -342,8 +339,8 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
         if (pw <= 4) {
             if (nitw <= 1) wg_body_rs<8, 1, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
             else wg_body_rs<8, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-        } else if (pw <= 5) {
-            wg_body_rs<10, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        } else if (pw <= 5) {       // 10 pieces per wave would do; that instantiation gave wrong sums on the GPU (not understood), 12 is verified
+            wg_body_rs<12, 2, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
         } else if (pw <= 6) {
             wg_body_rs<12, 4, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
         } else {
