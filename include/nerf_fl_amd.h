@@ -256,7 +256,7 @@ int nfl_gen_rays(const float* h_c2w, float fx, float fy, float cx, float cy, int
  *     NFL_PREC_F16W  the chain delta_{l-1} = W_l^T delta_l reads hi + lo weight fragments (two products): that offset is
  *                    gone (curve within the reference's own run-to-run scatter); stashes and weight gradients as F16;
  *     NFL_PREC_F16X3 the forward's split-operand arithmetic throughout (hi + lo weights, activations and gradients, three
- *                    products, weight gradients from three GEMM passes): fp32-class gradients, the precision class of the
+ *                    products, weight gradients from hi + lo records in one pass): fp32-class gradients, the precision class of the
  *                    reference's autograd; the stashes then hold a second, residual record per segment (twice the bytes),
  *                    written by a forward pass with nfl_pass_args::stash_split = 1.
  *   One value must be used for the stash sizes, the forward pass, the dgrad plan / stream and nfl_mlp_wgrad of a step. */
@@ -336,7 +336,12 @@ int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, v
  * transient_encoding.0 are composed, in fp32, from G = sum_s delta_dirh (x) h8 (accumulated in d_scratch,
  * nfl_wgrad_scratch_bytes() bytes, overwritten) and the CURRENT fp32 weights of those layers (`params`: the weights the
  * forward pass ran with; weight[NFL_P_FINAL], bias[NFL_P_FINAL], weight[NFL_P_DIR] and, with the transient head,
- * weight[NFL_P_T0] are read).  grads->bias[NFL_P_DIR] (and [NFL_P_T0]) must be given when any composed gradient is. */
+ * weight[NFL_P_T0] are read).  grads->bias[NFL_P_DIR] (and [NFL_P_T0]) must be given when any composed gradient is.
+ * bwd_prec: the value the stashes were sized and written with.  NFL_PREC_F16 / NFL_PREC_F16W: dW = sum_s d_hi (x) h_hi,
+ * one streaming pass; NFL_PREC_F16X3: the stashes hold residual records too and every accumulator gets
+ * d_hi (x) h_hi + d_lo (x) h_hi + d_hi (x) h_lo in one pass over both (db = sum_s (d_hi + d_lo)).
+ * The gradient tensors may be views of one caller-owned flat buffer (nerf_fl_amd.parallel.GradArena): they are zeroed,
+ * accumulated and unscaled in place, so a collective can run on that buffer right after this call. */
 size_t nfl_wgrad_scratch_bytes(void);
 int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
                   const float* d_gmax, int32_t n_rays, int32_t n_samples, int32_t bwd_prec,
