@@ -54,7 +54,6 @@ struct DgradArgs {
     int spr, rays_per_wg, nkp, n_seg_total;
     int rays_tiles;           // the stream carries the encoded-position / direction rows (gradient w.r.t. rays)
     int nfx_rt, ndir_rt;      // the field's frequency counts (<= the instantiation's; nfl_plan.h, "Encoder widths")
-    int n_ver, stream_bytes;  // rounding versions of the weight stream (nfl_plan.h: NFL_BWD_VERSIONS) and the bytes of one
 };
 
 struct DgradArgs;
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     const float inv_scale = 1.0f / scale;
 
     NflRingAux<C::SLOT, C::WBYTES, C::MAXP, NCB> ring;
-    ring.gsrc = A.packed + (size_t)(blockIdx.x % A.n_ver) * A.stream_bytes;     // this workgroup's rounding of the weights
+    ring.gsrc = A.packed;
     ring.chunk_off = chk_lds;
     ring.chunk_aux = aux_lds;
     ring.lds = smem + C::LDS_TAB;
@@ -643,8 +642,6 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     A.rays_tiles = hp->reserved_flags & 1;
     A.nfx_rt = hp->n_emb_xyz;
     A.ndir_rt = (hp->reserved_flags >> 8) & 0xff;
-    A.n_ver = ((hp->reserved_flags >> 16) & 0xff) > 1 ? ((hp->reserved_flags >> 16) & 0xff) : 1;
-    A.stream_bytes = hp->stream_bytes;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int rpw = (args->n_rays + ncu - 1) / ncu;

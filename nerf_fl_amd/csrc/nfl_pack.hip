@@ -36,12 +36,9 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(const PackBatch B) {
     const PackArgs& a = B.job[jb];
     const NflPlan& P = *a.plan;
     const int lane = threadIdx.x;
-    const int n_ver = ((P.reserved_flags >> 16) & 0xff) > 1 ? ((P.reserved_flags >> 16) & 0xff) : 1;   // dgrad streams: rounding versions
-    const int gblk = blockIdx.x - B.first_block[jb];
-    const int ver = gblk / P.total_ks < n_ver ? gblk / P.total_ks : 0;
-    const int gks = gblk < n_ver * P.total_ks ? gblk % P.total_ks : gblk - (n_ver - 1) * P.total_ks;   // k-step index in the stream
+    const int gks = blockIdx.x - B.first_block[jb];          // global k-step index in the stream
     if (gks >= P.total_ks) {
-        // bias table: blocks behind the streams, lanes 0..31
+        // bias table: blocks total_ks .. total_ks + n_rt - 1, lanes 0..31
         const int t = gks - P.total_ks;
         if (t >= P.n_rt || lane >= 32) return;
         const NflRowTile& rt = P.rt[t];
@@ -94,19 +91,7 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(const PackBatch B) {
             if (wcol != nullptr) w[j] = wcol[(size_t)(seg.col0 + m) * ldt];
         }
     }
-    char* dst = a.out + (size_t)ver * P.stream_bytes + (size_t)gks * P.ks_bytes + lane * 16;
-    if (n_ver > 1) {
-        // version `ver` of a dgrad stream rounds W + o ulp(W), o = (ver + 1/2) / V - 1/2 in (-1/2, 1/2): nfl_plan.h
-        const float o = ((float)ver + 0.5f) / (float)n_ver - 0.5f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float aw = fabsf(w[j]);
-            int e = (int)((__builtin_bit_cast(unsigned, aw) >> 23) & 0xffu) - 127;      // floor(log2 |w|) for normal fp32
-            e = e < -14 ? -14 : e;                                                        // fp16 subnormals share the spacing 2^-24
-            const float ulp = __builtin_bit_cast(float, (unsigned)(e - 10 + 127) << 23);
-            if (aw < 65504.f) w[j] += o * ulp;
-        }
-    }
+    char* dst = a.out + (size_t)gks * P.ks_bytes + lane * 16;
     if (P.elem == 0 && a.status) {
         bool bad = false;
 #pragma unroll
@@ -146,8 +131,7 @@ extern "C" int nfl_pack_fields(int32_t n_jobs, const nfl_pack_job* jobs, void* s
         if (!hp || !J.d_plan || !J.params || !J.d_packed || hp->magic != NFL_PLAN_MAGIC) return NFL_EINVAL;
         if (J.packed_bytes < (size_t)hp->packed_bytes) return NFL_ESMALL;
         B.first_block[j] = blocks;
-        const int n_ver = ((hp->reserved_flags >> 16) & 0xff) > 1 ? ((hp->reserved_flags >> 16) & 0xff) : 1;
-        blocks += n_ver * hp->total_ks + hp->n_rt;
+        blocks += hp->total_ks + hp->n_rt;
         B.job[j].plan = static_cast<const NflPlan*>(J.d_plan);
         B.job[j].params = *J.params;
         B.job[j].out = static_cast<char*>(J.d_packed);

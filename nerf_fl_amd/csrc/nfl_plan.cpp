@@ -174,15 +174,14 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, int bwd
         for (int t = 0; t < npe; ++t)
             b.ttile(32 * t, cx - 32 * t < 32 ? (cx - 32 * t > 0 ? cx - 32 * t : 0) : 32, -1,
                     [&](NflRowTile& r) { Builder::seg(r, 16, NFL_SEG_ACT, 0, W, NFL_P_XYZ1); });
-    const int n_ver = bwd_prec == NFL_PREC_F16 ? NFL_BWD_VERSIONS : 1;       // rounding versions of the stream (nfl_plan.h)
-    p->reserved_flags = (rays_grad ? 1 : 0) | (d->n_emb_dir << 8) | (n_ver << 16);
+    p->reserved_flags = (rays_grad ? 1 : 0) | (d->n_emb_dir << 8);
     p->n_rt_sigma = p->n_rt_static = p->n_rt;
     p->n_chunks_static = p->n_chunks;
     p->n_chunks_sigma = first_static_chunk;          // (field re-used by the dgrad stream)
     p->total_ks = b.ks_cursor;
     p->chunk_off[p->n_chunks] = p->total_ks * p->ks_bytes;
     p->stream_bytes = p->total_ks * p->ks_bytes;
-    p->bias_off = p->stream_bytes * n_ver;          // the versions back to back, then the (all-zero) bias table
+    p->bias_off = p->stream_bytes;
     p->packed_bytes = p->bias_off + p->n_rt * 32 * 4;
     if (p->n_rt > NFL_MAX_RT || p->n_chunks > NFL_MAX_CHUNKS) return NFL_EINVAL;
     return NFL_OK;

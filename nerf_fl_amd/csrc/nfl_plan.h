@@ -49,14 +49,6 @@
 // encoder runs in the next wider instantiation: the kernel still evaluates all its sin / cos features, but the packed
 // weights of the columns beyond 6 N + 3 are zero (the packer pads), so they contribute nothing -- forward, dgrad and wgrad
 // alike (their tile descriptors carry the true column counts).  The direction encoder has two k-steps: N_emb_dir <= 4.
-// The default backward's dgrad stream (NFL_PREC_F16, hi fragments only) is packed NFL_BWD_VERSIONS times, version v rounding
-// W + (v + 1/2 - V/2) / V ulp to fp16: workgroup b of the dgrad kernel reads version b mod V.  One fp16 rounding of the
-// transposed weights is the same wrong matrix for every sample of a step (and, late in training, for hundreds of steps): a
-// coherent error that Adam integrates into a training-curve offset (profiles/r03_psnr_backward_attribution.txt).  With V
-// roundings spread over the workgroups the MEAN matrix the batch sees is W to ulp / (2 V) instead of ulp / 2; what is left
-// differs from workgroup to workgroup, i.e. from sample to sample, and averages out like the gradients' own roundings.
-// The dispatcher deals consecutive workgroups to the 8 XCDs round-robin, so with V = 4 or 8 every XCD's L2 holds ONE version.
-#define NFL_BWD_VERSIONS 4
 #define NFL_MAX_EMB_XYZ 15
 #define NFL_MAX_EMB_DIR 4
 NFL_HD_EARLY int nfl_kernel_nfx(int n_emb_xyz) { return n_emb_xyz <= 10 ? 10 : 15; }       // instantiation that runs it
@@ -86,8 +78,7 @@ struct NflPlan {
     int32_t prec, nsplit;         // nsplit = 1 or 3 products; frags carry (nsplit==3 ? hi+lo : hi)
     int32_t elem;                 // 0: fp16 fragments (both streams now), 1: bf16 fragments
     int32_t is_bwd;               // 1: this is the dgrad (transposed) stream
-    int32_t reserved_flags;       // dgrad stream: bit 0 = carries the tiles for the gradient w.r.t. the rays; bits 8..15: n_emb_dir;
-                                  // bits 16..23: number of ROUNDING VERSIONS of the stream (NFL_BWD_VERSIONS; 0 / 1 = one)
+    int32_t reserved_flags;       // dgrad stream: bit 0 = carries the tiles for the gradient w.r.t. the rays; bits 8..15: n_emb_dir
     int32_t n_emb_xyz, nkp;       // nkp = k-steps of the encoded position in the kernel instantiation that runs this field (nfl_nkp_for)
     int32_t has_a, has_t, n_a, n_tau;
     int32_t n_rt, n_rt_sigma, n_rt_static;

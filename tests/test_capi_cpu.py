@@ -75,7 +75,7 @@ def test_bwd_plan_structure(L):
     assert L.nfl_bwd_plan_build(C.byref(d), 0, _lib.NFL_PREC_F16, buf, n) == 0
     hdr = np.frombuffer(buf.raw[:96], dtype=np.int32)
     # dgrad stream of the default backward (prec = NFL_PREC_F16): hi fragments only, no rays-gradient tiles
-    assert hdr[1] == 1 and hdr[2] == 1 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == (4 << 8 | 4 << 16)   # flags: no rays tiles | n_emb_dir << 8 | rounding versions << 16
+    assert hdr[1] == 1 and hdr[2] == 1 and hdr[3] == 0 and hdr[4] == 1 and hdr[5] == (4 << 8)      # flags: no rays tiles | n_emb_dir << 8
     n_rt, n_chunks, total_ks = hdr[12], hdr[15], hdr[18]
     # transposed row tiles: transient 4+12+1, rgb^T 4, appearance rows 2, h8 8 (dir' | t0' | sigma), 7 trunk layers x 8; the tiles of
     # the 4- and 8-tile groups travel two per chunk, the latent rows one per chunk
@@ -83,11 +83,11 @@ def test_bwd_plan_structure(L):
     assert n_chunks == (2 + 6 + 1) + 2 + 2 + 4 + 28
     assert hdr[16] == 9                                     # first chunk of the non-transient part (n_chunks_sigma re-used)
     assert total_ks == 4 * 3 + 12 * 8 + 8 + 4 * 1 + 2 * 8 + 8 * 17 + 56 * 16
-    assert L.nfl_bwd_packed_bytes(C.byref(d), 0, _lib.NFL_PREC_F16) == 4 * total_ks * 1024 + n_rt * 128     # four rounding versions of the stream
+    assert L.nfl_bwd_packed_bytes(C.byref(d), 0, _lib.NFL_PREC_F16) == total_ks * 1024 + n_rt * 128
     # with the gradient w.r.t. the rays: + direction rows (1 tile, 8 ks) + encoded-position rows of layers 5 and 1 (2 x 2 tiles, 16 ks)
     assert L.nfl_bwd_plan_build(C.byref(d), 1, _lib.NFL_PREC_F16, buf, n) == 0
     hdr2 = np.frombuffer(buf.raw[:96], dtype=np.int32)
-    assert hdr2[5] == (1 | 4 << 8 | 4 << 16) and hdr2[12] == n_rt + 5 and hdr2[15] == n_chunks + 5 and hdr2[18] == total_ks + 8 + 4 * 16
+    assert hdr2[5] == (1 | 4 << 8) and hdr2[12] == n_rt + 5 and hdr2[15] == n_chunks + 5 and hdr2[18] == total_ks + 8 + 4 * 16
     # exact-weight chain (F16W) and three-product backward (F16X3): the same tiles as hi + lo fragments (2 KiB per k-step),
     # one tile per chunk; `prec` tells the dgrad kernels apart
     for bp in (_lib.NFL_PREC_F16W, _lib.NFL_PREC_F16X3):
