@@ -57,9 +57,9 @@ typedef struct nfl_field_desc {
     int32_t n_emb_xyz;          /* PosEmbedding freqs for xyz: 1..15 (opt.py:25 default 10; test_phototourism.ipynb 15)  */
     int32_t n_emb_dir;          /* PosEmbedding freqs for dir: 1..4 (opt.py:27 default 4)                                */
     int32_t encode_appearance;  /* NeRF-A head: dir layer sees n_a extra inputs (nerf.py:115,134)             */
-    int32_t n_a;                /* 48                                                                         */
+    int32_t n_a;                /* 1..48 (opt.py --N_a, default 48)                                           */
     int32_t encode_transient;   /* NeRF-U head (nerf.py:141-151)                                              */
-    int32_t n_tau;              /* 16                                                                         */
+    int32_t n_tau;              /* 1..16 (opt.py --N_tau, default 16)                                         */
     float   beta_min;           /* added after compositing (rendering.py:185)                                 */
     int32_t reserved;
 } nfl_field_desc;

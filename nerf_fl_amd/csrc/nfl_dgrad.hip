@@ -54,6 +54,7 @@ struct DgradArgs {
     int spr, rays_per_wg, nkp, n_seg_total;
     int rays_tiles;           // the stream carries the encoded-position / direction rows (gradient w.r.t. rays)
     int nfx_rt, ndir_rt;      // the field's frequency counts (<= the instantiation's; nfl_plan.h, "Encoder widths")
+    int n_a, n_tau;           // widths of the latent codes (<= 48 / 16)
 };
 
 struct DgradArgs;
@@ -534,9 +535,9 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const size_t row = K->a.d_latent_row ? (size_t)K->a.d_latent_row[ray[cb]] : (size_t)ray[cb];     // table row or ray
-                gt[cb] = (K->a.d_g_t_emb && seg_ok[cb]) ? K->a.d_g_t_emb + row * 16 : nullptr;
+                gt[cb] = (K->a.d_g_t_emb && seg_ok[cb]) ? K->a.d_g_t_emb + row * K->n_tau : nullptr;
             }
-            dg_latent_tile<8, NCB, M>(ring, Q, 8, gt, 16, h, c, inv_scale);
+            dg_latent_tile<8, NCB, M>(ring, Q, 8, gt, K->n_tau, h, c, inv_scale);
         }
         dg_tiles<WB, true, 4, 1, 0, 0, NCB, M>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
         K = nfl_dg_kargs();
@@ -546,11 +547,11 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 const size_t row = K->a.d_latent_row ? (size_t)K->a.d_latent_row[ray[cb]] : (size_t)ray[cb];
-                ga[cb] = (K->a.d_g_a_emb && seg_ok[cb]) ? K->a.d_g_a_emb + row * 48 : nullptr;
+                ga[cb] = (K->a.d_g_a_emb && seg_ok[cb]) ? K->a.d_g_a_emb + row * K->n_a : nullptr;
                 ga2[cb] = ga[cb] ? ga[cb] + 32 : nullptr;
             }
-            dg_latent_tile<8, NCB, M>(ring, Q, 0, ga, 32, h, c, inv_scale);
-            dg_latent_tile<8, NCB, M>(ring, Q, 0, ga2, 16, h, c, inv_scale);
+            dg_latent_tile<8, NCB, M>(ring, Q, 0, ga, K->n_a < 32 ? K->n_a : 32, h, c, inv_scale);
+            dg_latent_tile<8, NCB, M>(ring, Q, 0, ga2, K->n_a - 32, h, c, inv_scale);        // <= 0 rows for codes of <= 32
         }
         K = nfl_dg_kargs();
         if (K->rays_tiles) dg_pe_tile<4, 0, 8, NCB, M>(ring, Q, 0, h, dth, dtl, pw_lds + 16, gd);
@@ -642,6 +643,8 @@ static int launch_dgrad(const NflPlan* hp, const void* d_plan, const void* d_pac
     A.rays_tiles = hp->reserved_flags & 1;
     A.nfx_rt = hp->n_emb_xyz;
     A.ndir_rt = (hp->reserved_flags >> 8) & 0xff;
+    A.n_a = hp->n_a;
+    A.n_tau = hp->n_tau;
     int dev = 0, ncu = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
     int rpw = (args->n_rays + ncu - 1) / ncu;

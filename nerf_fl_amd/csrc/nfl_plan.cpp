@@ -107,8 +107,9 @@ static int check_desc(const nfl_field_desc* d) {
     if (!d) return NFL_EINVAL;
     if (d->n_emb_xyz < 1 || d->n_emb_xyz > NFL_MAX_EMB_XYZ) return NFL_EINVAL;
     if (d->n_emb_dir < 1 || d->n_emb_dir > NFL_MAX_EMB_DIR) return NFL_EINVAL;
-    if (d->encode_appearance && d->n_a != 48) return NFL_EINVAL;
-    if (d->encode_transient && d->n_tau != 16) return NFL_EINVAL;
+    // latent widths (opt.py: --N_a 48, --N_tau 16): narrower codes run in the same 3 / 1 k-steps on zero-padded weight columns
+    if (d->encode_appearance && (d->n_a < 1 || d->n_a > 48)) return NFL_EINVAL;
+    if (d->encode_transient && (d->n_tau < 1 || d->n_tau > 16)) return NFL_EINVAL;
     return NFL_OK;
 }
 
@@ -149,7 +150,7 @@ extern "C" int nfl_plan_fill_bwd(const nfl_field_desc* d, int rays_grad, int bwd
                 [&](NflRowTile& r) { Builder::seg(r, 1, NFL_SEG_NAT, 0, 3, NFL_P_RGB); }, pair && (t & 1));
     if (p->has_a)
         for (int t = 0; t < 2; ++t)
-            b.ttile(W + cd + 32 * t, t == 0 ? 32 : p->n_a - 32, -1,
+            b.ttile(W + cd + 32 * t, t == 0 ? (p->n_a < 32 ? p->n_a : 32) : (p->n_a > 32 ? p->n_a - 32 : 0), -1,
                     [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR); });
     if (rays_grad)      // rows of W_dir^T that multiply the encoded view direction
         b.ttile(W, cd, -1, [&](NflRowTile& r) { Builder::seg(r, 8, NFL_SEG_ACT, 0, H, NFL_P_DIR); });

@@ -92,6 +92,7 @@ struct RenderArgs {
     int n_points, emb_stride;   // NFL_MODE_EMBED: rows / row stride (floats) of a.d_embedded
     int nfx_rt, ndir_rt;        // the field's frequency counts (<= the instantiation's: nfl_plan.h, "Encoder widths")
     int cx, cd;                 // 6 nfx_rt + 3, 6 ndir_rt + 3: widths of the encoded position / direction
+    int n_a, n_tau;             // widths of the appearance / transient codes (<= 48 / 16; narrower: the k-steps are zero-padded)
     int gen_rays;               // rays come from `cam` (nfl_pass_args::h_cam), not from a.d_rays
     nfl_camera cam;
 };
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
 #pragma unroll
                             for (int j = 0; j < 8; ++j) {
                                 const int f = 16 * (ks < 2 ? ks : ks - 2) + 8 * h + j;
-                                v[j] = ks < 2 ? (f < K->cd ? xr[f] : 0.f) : xr[K->cd + f];
+                                v[j] = ks < 2 ? (f < K->cd ? xr[f] : 0.f) : (f < K->n_a ? xr[K->cd + f] : 0.f);
                             }
                             nfl_split8<NP>(v, D[ks][cb]);
                         }
@@ -920,12 +921,20 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                     nfl_pe_kstep<4, NP, LO>(1, h, raw, th, tl, pw_lds + 16, D[1][cb], STASH ? sd + 1024 : nullptr);
                     __builtin_amdgcn_sched_barrier(0);
                     if (K->has_a) {
-                        const float* ap = K->a.d_a_emb + (size_t)s_ray[cb] * 48 + 8 * h;
+                        const int na = K->n_a;
+                        const float* ap = K->a.d_a_emb + (size_t)s_ray[cb] * na + 8 * h;
 #pragma unroll
                         for (int ks = 0; ks < 3; ++ks) {
-                            const f4v v0 = *reinterpret_cast<const f4v*>(ap + 16 * ks);
-                            const f4v v1 = *reinterpret_cast<const f4v*>(ap + 16 * ks + 4);
-                            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            float v[8];
+                            if (na == 48) {          // the reference's default width: rows are 16-byte aligned
+                                const f4v v0 = *reinterpret_cast<const f4v*>(ap + 16 * ks);
+                                const f4v v1 = *reinterpret_cast<const f4v*>(ap + 16 * ks + 4);
+                                v[0] = v0[0]; v[1] = v0[1]; v[2] = v0[2]; v[3] = v0[3];
+                                v[4] = v1[0]; v[5] = v1[1]; v[6] = v1[2]; v[7] = v1[3];
+                            } else {                  // narrower code: scalar loads, zeros beyond its width
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[j] = 16 * ks + 8 * h + j < na ? ap[16 * ks + j] : 0.f;
+                            }
                             nfl_split8<NP>(v, D[2 + ks][cb]);
                             if (STASH) nfl_stash8<LO>(v, sd + (2 + ks) * 1024);
                         }
@@ -956,12 +965,12 @@ __global__ __launch_bounds__(256, 1) void nfl_render_kernel(const RenderArgs A) 
                 for (int cb = 0; cb < NCB; ++cb) {
                     const int tb = s_ray[cb] * 32 + s_idx[cb];
                     const float* tp = EMBED ? K->a.d_embedded + (size_t)(tb < K->n_points ? tb : K->n_points - 1) * K->emb_stride
-                                                  + K->cx + K->cd + (K->has_a ? 48 : 0) + 8 * h
-                                            : K->a.d_t_emb + (size_t)s_ray[cb] * 16 + 8 * h;
+                                                  + K->cx + K->cd + (K->has_a ? K->n_a : 0) + 8 * h
+                                            : K->a.d_t_emb + (size_t)s_ray[cb] * K->n_tau + 8 * h;
                     float v[8];
-                    if constexpr (EMBED) {          // rows of the encoded matrix are not 16-byte aligned
+                    if (EMBED || K->n_tau != 16) {  // rows of the encoded matrix / of a narrower code are not 16-byte aligned
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = tp[j];
+                        for (int j = 0; j < 8; ++j) v[j] = 8 * h + j < K->n_tau ? tp[j] : 0.f;
                     } else {
                         const f4v v0 = *reinterpret_cast<const f4v*>(tp);
                         const f4v v1 = *reinterpret_cast<const f4v*>(tp + 4);
@@ -1224,6 +1233,8 @@ static int nfl_launch_render_t(const NflPlan* hp, const void* d_plan, const void
     A.ndir_rt = (hp->ld[NFL_P_DIR] - NFL_W - hp->n_a - 3) / 6;
     A.cx = 6 * A.nfx_rt + 3;
     A.cd = 6 * A.ndir_rt + 3;
+    A.n_a = hp->n_a;
+    A.n_tau = hp->n_tau;
     memset(&A.cam, 0, sizeof(A.cam));
     if ((args->h_cam != nullptr || args->d_cam != nullptr) && MODE != NFL_MODE_EMBED) {
         A.gen_rays = 1;

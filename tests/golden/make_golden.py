@@ -252,7 +252,8 @@ def train_reference(steps=400, R=512, n_vocab=20, lr=1e-3):
 def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, use_disp=False,
                 perturb=0.0, noise_std=0.0, test_time=False, n_vocab=20, kwargs_mode="ts",
                 output_transient=None, grads=False, rays_grad=False, near=2.0, far=6.0, seed=11,
-                n_emb_xyz=10, barf_epoch=None, rays_kind="blender", view_dir=False, beta_min=0.1, n_emb_dir=4):
+                n_emb_xyz=10, barf_epoch=None, rays_kind="blender", view_dir=False, beta_min=0.1, n_emb_dir=4,
+                n_a=48, n_tau=16):
     """fine: None | 'base' | 'a' | 'at'.  rays_kind 'photo': per-ray near/far (phototourism); view_dir: pass a
     `view_dir` kwarg that differs from rays_d (rendering.py:236-238)."""
     spec_c = orc.FieldSpec("coarse", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir)
@@ -267,11 +268,12 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
     cfg = dict(R=R, S=S, I=I, fine=fine, regime=regime, white_back=white_back, use_disp=use_disp,
                perturb=perturb, noise_std=noise_std, test_time=test_time, n_vocab=n_vocab,
                kwargs_mode=kwargs_mode, output_transient=output_transient, seed=seed,
-               n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, beta_min=beta_min, barf_epoch=barf_epoch, rays_kind=rays_kind)
+               n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, beta_min=beta_min, barf_epoch=barf_epoch, rays_kind=rays_kind,
+               n_a=n_a, n_tau=n_tau)
     spec_f = None
     if fine is not None:
         spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, encode_appearance=fine in ("a", "at"),
-                               encode_transient=fine == "at", beta_min=beta_min)
+                               encode_transient=fine == "at", beta_min=beta_min, n_a=n_a, n_tau=n_tau)
         models["fine"] = ref_field(spec_f, seed + 1, regime, refine_pose=barf)
     rays = orc.make_rays_photo(R, seed + 2) if rays_kind == "photo" else orc.make_rays(R, seed + 2, near, far)
     rng = np.random.default_rng(seed + 3)
@@ -283,15 +285,15 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
     a_emb = t_emb = None
     if spec_f is not None and spec_f.encode_appearance:
         table_a = (torch.from_numpy(np.load(TRAINED)["table_a"]) if regime == "trained"
-                   else orc.make_embedding_table(n_vocab, 48, seed + 4))
-        emb = torch.nn.Embedding(n_vocab, 48)
+                   else orc.make_embedding_table(n_vocab, n_a, seed + 4))
+        emb = torch.nn.Embedding(n_vocab, n_a)
         emb.weight.data.copy_(table_a)
         embeddings["a"] = emb
         a_emb = table_a[ts].clone()
     if spec_f is not None and spec_f.encode_transient:
         table_t = (torch.from_numpy(np.load(TRAINED)["table_t"]) if regime == "trained"
-                   else orc.make_embedding_table(n_vocab, 16, seed + 5))
-        emb = torch.nn.Embedding(n_vocab, 16)
+                   else orc.make_embedding_table(n_vocab, n_tau, seed + 5))
+        emb = torch.nn.Embedding(n_vocab, n_tau)
         emb.weight.data.copy_(table_t)
         embeddings["t"] = emb
         t_emb = table_t[ts].clone()
@@ -455,6 +457,10 @@ RENDER_CASES = [
                              n_emb_xyz=3, n_emb_dir=1, seed=34)),
     ("g18_emb14_3_stoch", dict(R=48, S=64, I=64, fine="a", white_back=True, perturb=1.0, noise_std=1.0, n_emb_xyz=14,
                                n_emb_dir=3, seed=35)),
+    # other latent widths (opt.py --N_a / --N_tau): 24 / 8 through the tables, 40 / 5 through the a_embedded / t_embedded kwargs
+    ("g18_na24_tau8", dict(R=48, S=32, I=32, fine="at", white_back=True, grads=True, n_a=24, n_tau=8, seed=37)),
+    ("g18_na40_tau5_emb", dict(R=48, S=32, I=32, fine="at", white_back=False, grads=True, kwargs_mode="embedded", n_a=40, n_tau=5,
+                               n_emb_xyz=12, seed=38)),
     # view_dir given AND a gradient w.r.t. the rays (rendering.py:236-238: the direction encoding then does not depend on rays)
     ("g16_view_dir_rays", dict(R=48, S=32, I=32, fine="a", white_back=True, view_dir=True, grads=True, rays_grad=True, seed=36)),
     ("g17_trained_cfg2", dict(R=64, S=64, I=64, fine="base", white_back=True, regime="trained", grads=True, seed=21)),

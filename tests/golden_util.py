@@ -28,7 +28,7 @@ def embedding_table(cfg, which):
     """The (N_vocab, dim) latent table a fixture was generated with; which = 'a' | 't'."""
     if cfg["regime"] == "trained":
         return torch.from_numpy(np.load(TRAINED, allow_pickle=False)["table_" + which])
-    dim, off = (48, 4) if which == "a" else (16, 5)
+    dim, off = (cfg.get("n_a", 48), 4) if which == "a" else (cfg.get("n_tau", 16), 5)
     return orc.make_embedding_table(cfg["n_vocab"], dim, cfg["seed"] + off)
 
 
@@ -49,7 +49,8 @@ def specs_and_params(cfg):
     P_c = field_params(spec_c, cfg["seed"], cfg["regime"])
     spec_f = P_f = None
     if cfg["fine"] is not None:
-        spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, encode_appearance=cfg["fine"] in ("a", "at"),
+        spec_f = orc.FieldSpec("fine", n_emb_xyz=n_emb_xyz, n_emb_dir=n_emb_dir, n_a=cfg.get("n_a", 48), n_tau=cfg.get("n_tau", 16),
+                               encode_appearance=cfg["fine"] in ("a", "at"),
                                encode_transient=cfg["fine"] == "at", beta_min=cfg["beta_min"])
         P_f = field_params(spec_f, cfg["seed"] + 1, cfg["regime"])
     return spec_c, P_c, spec_f, P_f

@@ -123,13 +123,20 @@ def test_encoder_widths(L):
             a * b + a for a, b in [(256, 6 * n_xyz + 3)] + [(256, 256)] * 3 + [(256, 256 + 6 * n_xyz + 3)] + [(256, 256)] * 4
             + [(128, 256 + 6 * n_dir + 3 + 48), (1, 256), (3, 128), (128, 256 + 16)] + [(128, 128)] * 3 + [(1, 128), (3, 128), (1, 128)])
         assert L.nfl_act_stash_bytes(C.byref(d), 2, 64, _lib.NFL_PREC_F16) == 2 * 2 * (nkp + 174) * 1024 + 4096 + 2 * 2 * 84 * 256
+    # latent widths (opt.py --N_a / --N_tau): 1..48 / 1..16, zero-padded into the same k-steps
+    for n_a, n_tau in ((24, 8), (40, 5), (1, 1), (33, 16)):
+        d = _lib.FieldDesc(10, 4, 1, n_a, 1, n_tau, 0.1, 0)
+        n = L.nfl_plan_bytes(C.byref(d))
+        buf = C.create_string_buffer(n)
+        assert L.nfl_plan_build(C.byref(d), _lib.NFL_PREC_F16X3, buf, n) == 0 and L.nfl_bwd_plan_build(C.byref(d), 0, _lib.NFL_PREC_F16, buf, n) == 0
     name = lambda n: L.nfl_render_kernel_name(_lib.NFL_PREC_F16X3, n).decode()
     assert name(6) == name(10) != name(12) == name(15)
 
 
 def test_unsupported_configs_rejected(L):
     for bad in (_lib.FieldDesc(16, 4, 0, 48, 0, 16, 0.1, 0), _lib.FieldDesc(0, 4, 0, 48, 0, 16, 0.1, 0),
-                _lib.FieldDesc(10, 5, 0, 48, 0, 16, 0.1, 0), _lib.FieldDesc(10, 4, 1, 32, 0, 16, 0.1, 0)):
+                _lib.FieldDesc(10, 5, 0, 48, 0, 16, 0.1, 0), _lib.FieldDesc(10, 4, 1, 49, 0, 16, 0.1, 0),
+                _lib.FieldDesc(10, 4, 1, 48, 1, 17, 0.1, 0), _lib.FieldDesc(10, 4, 1, 0, 0, 16, 0.1, 0)):
         n = L.nfl_plan_bytes(C.byref(bad))
         buf = C.create_string_buffer(n)
         assert L.nfl_plan_build(C.byref(bad), 0, buf, n) == -1

@@ -20,7 +20,7 @@ def test_fused_loss_matches_unfused(name):
     dev = gpu_util.DEV
     models = {"coarse": gpu_util.module_from(spec_c, P_c), "fine": gpu_util.module_from(spec_f, P_f)}
     emb = gpu_util.make_embeddings(spec_c.n_emb_xyz, False)
-    for k, dim in (("a", 48), ("t", 16)):
+    for k, dim in (("a", cfg.get("n_a", 48)), ("t", cfg.get("n_tau", 16))):
         if kw.get(k + "_emb") is not None:
             table = gu.embedding_table(cfg, k)
             e = torch.nn.Embedding(table.shape[0], dim).to(dev)

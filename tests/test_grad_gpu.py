@@ -31,6 +31,7 @@ CASES = ["g11_grad_cfg1", "g11_grad_cfg2", "g11_grad_cfg3", "g11_grad_cfg3_ts", 
          "g15_photo_grad", "g15_photo_stoch",                # configs[3]: N_vocab 1500 tables, per-ray near/far, R 1024
          "g16_view_dir",                                     # view_dir kwarg
          "g16_view_dir_rays",                                # view_dir AND d/d rays (the direction encoding is then data)
+         "g18_na24_tau8", "g18_na40_tau5_emb",               # other latent widths (opt.py --N_a / --N_tau), tables and kwargs
          "g18_emb6_2", "g18_emb12_4", "g18_emb3_1_barf",     # other encoder widths (opt.py:25-28): xyz 6 / dir 2, 12 / 4 (+ rays), 3 / 1 (BARF + rays)
          "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch"]   # weights after 400 reference Adam steps
 
@@ -113,7 +114,7 @@ def _run_case(name):
                 leaves[k] = kw[k].to(dev).requires_grad_(True)
                 extra[kk] = leaves[k]
     else:
-        for k, dim in (("a", 48), ("t", 16)):
+        for k, dim in (("a", cfg.get("n_a", 48)), ("t", cfg.get("n_tau", 16))):
             if kw.get(k + "_emb") is not None:
                 table = gu.embedding_table(cfg, k)
                 e = torch.nn.Embedding(table.shape[0], dim).to(dev)

@@ -75,7 +75,8 @@ def test_render_forward(name):
 
 GRAD = gu.golden_names("g11_") + ["g12_stoch_grad", "g14_barf_e6", "g14_barf_e9", "g15_photo_grad", "g15_photo_stoch",
                                    "g16_view_dir", "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch",
-                                   "g16_view_dir_rays", "g18_emb6_2", "g18_emb12_4", "g18_emb3_1_barf"]
+                                   "g16_view_dir_rays", "g18_emb6_2", "g18_emb12_4", "g18_emb3_1_barf",
+                                   "g18_na24_tau8", "g18_na40_tau5_emb"]
 
 
 @pytest.mark.parametrize("name", GRAD)
@@ -118,7 +119,7 @@ def test_render_gradients(name):
             assert abs(g.norm().item() - exp.item()) <= 2e-4 * max(exp.item(), 1e-6) + 1e-7, key
     if "grad.table_a" in a:   # scatter of the per-ray latent grads into the table
         ts = a["ts"]
-        for k, dim in (("a", 48), ("t", 16)):
+        for k, dim in (("a", cfg.get("n_a", 48)), ("t", cfg.get("n_tau", 16))):
             if f"grad.table_{k}" not in a:
                 continue
             tab = torch.zeros(cfg["n_vocab"], dim).index_add_(0, ts, leaves[f"{k}_emb"].grad)
