@@ -144,6 +144,6 @@ def test_graphed_step_uses_the_given_loss_constants():
     res = render_rays(models, emb, rays, ts, S, use_disp, 0.0, 0.0, I, 32768, white_back, False, loss_target=target,
                       loss_coef=0.5, lambda_u=0.2)
     dflt = render_rays(models, emb, rays, ts, S, use_disp, 0.0, 0.0, I, 32768, white_back, False, loss_target=target)
-    want, other = float(res["_nerfw_loss"]), float(dflt["_nerfw_loss"])
+    want, other = res["_nerfw_loss"].item(), dflt["_nerfw_loss"].item()
     assert abs(want - other) > 1e-3 * abs(other)                   # the constants matter on this fixture
     assert abs(float(loss) - want) <= 1e-5 * max(1.0, abs(want))
