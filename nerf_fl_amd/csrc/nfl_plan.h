@@ -141,11 +141,14 @@ NFL_HD constexpr size_t nfl_msk_offset(size_t n_seg, int nkp, int mult = 1) { re
 // compositing backward left in d_gmax) to [2^5, 2^6).  fp16 overflows at 65504, so intermediate gradients may
 // grow 1024x over the largest head gradient; anything 2^-19 below it is still a normal fp16 (2^-29: subnormal).
 // dgrad and wgrad both derive the scale from the same words, so they agree bit for bit.
+#ifndef NFL_LOSS_SCALE_LOG2
+#define NFL_LOSS_SCALE_LOG2 5
+#endif
 NFL_HD float nfl_loss_scale_from_bits(unsigned bits) {
     int e = (int)((bits >> 23) & 0xffu) - 127;        // floor(log2(gmax)) for normal values
     if (bits == 0u || e < -100) return 1.0f;           // no gradient at all (or denormal): nothing to scale
     if (e > 100) e = 100;
-    const unsigned sbits = (unsigned)(127 + 5 - e) << 23;
+    const unsigned sbits = (unsigned)(127 + NFL_LOSS_SCALE_LOG2 - e) << 23;
     union { unsigned u; float f; } cvt;
     cvt.u = sbits;
     return cvt.f;
