@@ -18,8 +18,20 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("backward", ["f16", "f16w", "f16x3"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_gradients_vs_oracle_autograd(name):
+def test_gradients_vs_oracle_autograd(name, backward):
+    """Every backward arithmetic on the shapes the fixtures do not have: ragged sample counts (padded segments write the
+    scratch record of the -- possibly split -- gradient stash), rays spanning several tiles, heads switched off."""
+    import nerf_fl_amd
+    nerf_fl_amd.set_precision("f16x3", backward=backward)
+    try:
+        _gradients_vs_oracle_autograd(name)
+    finally:
+        nerf_fl_amd.set_precision("f16x3", backward="f16")
+
+
+def _gradients_vs_oracle_autograd(name):
     import gpu_util
     from nerf_fl_amd import PosEmbedding, render_rays
     c = CASES[name]

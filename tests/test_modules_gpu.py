@@ -71,6 +71,28 @@ def test_field_forward_ragged(B):
         assert ((got - exp).abs() / exp.abs().clamp(min=1.0)).max().item() <= TOL
 
 
+@pytest.mark.parametrize("n_xyz,n_dir,n_a,n_tau", [(6, 2, 24, 8), (12, 3, 40, 5), (3, 1, 48, 16), (15, 4, 1, 1)])
+def test_field_forward_other_widths(n_xyz, n_dir, n_a, n_tau):
+    """NeRF.forward on encoded inputs for other encoder / latent widths (opt.py:25-28, --N_a, --N_tau): narrower inputs run in
+    the next wider kernel instantiation on zero-padded weights (nfl_plan.h); against the pinned oracle."""
+    spec = orc.FieldSpec("fine", n_emb_xyz=n_xyz, n_emb_dir=n_dir, encode_appearance=True, n_a=n_a, encode_transient=True, n_tau=n_tau)
+    P = orc.make_field_params(spec, 91, "default")
+    B = 77
+    g = torch.Generator().manual_seed(n_xyz * 100 + n_a)
+    x = torch.cat([orc.posenc(torch.rand(B, 3, generator=g) * 4 - 2, n_xyz),
+                   orc.posenc(torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=-1), n_dir),
+                   torch.randn(B, n_a, generator=g), torch.randn(B, n_tau, generator=g)], 1)
+    nerf_fl_amd.set_precision("f16x3")
+    m = module_from(spec, P)
+    cx = 6 * n_xyz + 3
+    for so, ot, cols in ((False, True, 9), (False, False, 4), (True, False, 1)):
+        with torch.no_grad():
+            got = m(x.to(DEV), sigma_only=so, output_transient=ot).cpu()
+            exp = orc.field_forward_packed(spec, P, x if not so else x[:, :cx], sigma_only=so, output_transient=ot)
+        assert got.shape == (B, cols) == tuple(exp.shape)
+        assert ((got - exp).abs() / exp.abs().clamp(min=1.0)).max().item() <= TOL
+
+
 def test_module_forward_rejects_cpu_and_grad():
     m = module_from(orc.FieldSpec("coarse"), orc.make_field_params(orc.FieldSpec("coarse"), 1, "default"))
     with pytest.raises(RuntimeError):
