@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NFL_ABI_VERSION 8
+#define NFL_ABI_VERSION 9
 #define NFL_GMAX_SLOTS 1024
 
 enum {
@@ -315,6 +315,9 @@ typedef struct nfl_dgrad_args {
     const float* d_pe_w_xyz;        /* as given to the forward pass (NULL = ones)          */
     const float* d_pe_w_dir;
     const float* d_gmax;            /* (1024) from nfl_composite_backward: fixes the loss scale of this pass */
+    uint32_t rounding_seed;         /* NFL_PREC_F16 / NFL_PREC_F16W round their fp16 gradients STOCHASTICALLY (unbiased; see
+                                       nfl_mlp_dgrad below).  The draws are a function of (this seed, the work-item, *d_gmax):
+                                       the same seed on the same data reproduces them, another seed gives an independent set */
 } nfl_dgrad_args;
 int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
                   const nfl_dgrad_args* args, void* stream);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = ((os.environ.get("NFL_LIB") if os.environ.get("NERF_FL_AMD_DEV") == "1" else None)
             or os.path.join(_HERE, "libnerf_fl_amd.so"))
 
-NFL_ABI_VERSION = 8
+NFL_ABI_VERSION = 9
 NFL_GMAX_SLOTS = 1024
 NFL_PREC_F16X3 = 0
 NFL_PREC_F16 = 1
@@ -101,7 +101,7 @@ class DgradArgs(C.Structure):
         ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("use_transient", C.c_int32), ("dir_is_data", C.c_int32),
         ("d_g_a_emb", C.c_void_p), ("d_g_t_emb", C.c_void_p), ("d_latent_row", C.c_void_p),
         ("d_g_rays", C.c_void_p), ("d_rays", C.c_void_p), ("d_z", C.c_void_p),
-        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p), ("d_gmax", C.c_void_p),
+        ("d_pe_w_xyz", C.c_void_p), ("d_pe_w_dir", C.c_void_p), ("d_gmax", C.c_void_p), ("rounding_seed", C.c_uint32),
     ]
 
 

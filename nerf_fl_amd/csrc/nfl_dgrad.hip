@@ -208,6 +208,39 @@ struct NflRingAux {
     }
 };
 
+// ---- stochastic rounding of the gradients (single-image modes f16 / f16w) ----------------------------------------------
+// A gradient that is rounded to fp16 to the NEAREST value carries an error that is a fixed function of the value; over the
+// ~1e6 samples of a step those errors do not average out of the weight-gradient sums the way independent noise would, and
+// the fit's loss curve ends up below the reference's (profiles/r03_psnr_backward_attribution.txt: the round-3 measurements).
+// v_cvt_sr_f16_f32 rounds up with probability = the discarded fraction (it compares the 13 discarded mantissa bits with
+// bits 19..31 of its third operand: profiles/tools/sr_probe.hip), so E[rounded] = value and the errors of different samples
+// are independent.  The random words come from a 24-bit LCG per lane (v_mad_u32_u24: one full-rate instruction; the product's
+// bits 24..31 are folded back over the weak low bits), one step per pair-op; each conversion takes its own 13-bit window.
+struct DgRng {
+    unsigned s;
+    NFL_DEV unsigned next() {
+        s = __umul24(s, 0x9E3775u) + 0x6D2B79F5u;       // multiplier = 1 mod 4, odd increment: full period in the low 24 bits
+        return s ^ (s >> 16);
+    }
+};
+NFL_DEV unsigned dg_sr_pack(float x0, float x1, unsigned r0, unsigned r1) {
+#ifdef NFL_DIAG_RN_DELTA
+    return nfl_pack2<_Float16>(x0, x1);
+#endif
+    unsigned h;
+    asm("v_cvt_sr_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(r0));                    // writes bits 0..15
+    asm("v_cvt_sr_f16_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(h) : "v"(x1), "v"(r1));     // writes bits 16..31, keeps the rest
+    return h;
+}
+NFL_DEV float dg_sr_round(float x, unsigned r) {
+#ifdef NFL_DIAG_RN_DELTA
+    return (float)(_Float16)x;
+#endif
+    unsigned h;
+    asm("v_cvt_sr_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x), "v"(r));
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+}
+
 template <int NCB>
 NFL_DEV void dg_zero(f16v (&acc)[NCB]) {
 #pragma unroll
@@ -227,10 +260,12 @@ struct DgEpi {
     char* const (&gst)[NCB];
     const int slot;
     static constexpr int LO = NP == 2 ? NFL_GRD_SLOTS * 1024 : 0;     // the residual record follows the hi record (nfl_plan.h)
+    DgRng& rng;               // per-lane generator behind the stochastic rounding of the single-image modes
 
     template <int OP>
     NFL_DEV void pair() {
         constexpr int s = OP / 4, j = 2 * (OP % 4);
+        unsigned rw = 0u;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
@@ -240,7 +275,9 @@ struct DgEpi {
                 hi = nfl_split_pair<_Float16>(x0, x1, l0, l1);
                 lo = nfl_pack2<_Float16>(l0, l1);
             } else {
-                hi = nfl_pack2<_Float16>(x0, x1);
+                // one generator step per pair-op serves all its conversions: 13-bit windows of the word, 8 bits apart
+                if (cb == 0) rw = rng.next();
+                hi = dg_sr_pack(x0, x1, __builtin_amdgcn_alignbit(rw, rw, 16 * cb), __builtin_amdgcn_alignbit(rw, rw, 16 * cb + 8));
             }
             if (MASK) {
                 // the forward's mask word has the pair's two predicates at bits 2*OP and 16 + 2*OP: shifted down
@@ -287,7 +324,7 @@ template <int WB, bool MASK, int NRT, int NKA, int NKB, int NKC, int NCB, class 
 NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
                       const h8 (&inA)[NA][NCB][M::NP], int ksA, const h8 (&inB)[NB][NCB][M::NP], int ksB,
                       const h8 (&inC)[NC][NCB][M::NP], int ksC,
-                      h8 (&out)[NOUT][NCB][M::NP], int out_ks0, char* const (&gst)[NCB], int slot0) {
+                      h8 (&out)[NOUT][NCB][M::NP], int out_ks0, char* const (&gst)[NCB], int slot0, DgRng& rng) {
     constexpr int NK = NKA + NKB + NKC;
     constexpr int NP = M::NP, TPC = M::TPC;
     f16v acc[2][NCB];
@@ -319,7 +356,7 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
             for (int cb = 0; cb < NCB; ++cb) mk[i & 1][cb] = mkq[cb][i & 3];
         }
         if constexpr (i > 0) {
-            DgEpi<MASK, NOUT, NCB, NP> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1)};
+            DgEpi<MASK, NOUT, NCB, NP> epi{acc[(i - 1) & 1], mk[(i - 1) & 1], out, out_ks0 + 2 * (i - 1), gst, slot0 + 2 * (i - 1), rng};
             nfl_tile_p<M::PRODS, NP, NCB, NK, P0, h8>(acc[i & 1], wl, P0, getb, epi, ring);
             ring.note(2 * NCB * NP);     // the epilogue's stash stores, issued at the tile's last k-step
         } else {
@@ -331,7 +368,7 @@ NFL_DEV void dg_tiles(Ring& ring, int wave_mask_off,
         else if constexpr ((i & 1) == 0) ring.template pieces<NK, TS>();
         else ring.template pieces<TS + NK, Ring::MAXP>();
     });
-    DgEpi<MASK, NOUT, NCB, NP> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1)};
+    DgEpi<MASK, NOUT, NCB, NP> last{acc[(NRT - 1) & 1], mk[(NRT - 1) & 1], out, out_ks0 + 2 * (NRT - 1), gst, slot0 + 2 * (NRT - 1), rng};
     last.all();
     ring.note(2 * NCB * NP);
 }
@@ -462,6 +499,9 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
 #endif
 
+    // generator of the stochastic rounding: one stream per lane, mixed with the pass's gradient maximum (so the draws
+    // differ from step to step) and the caller's seed (independent repetitions of a fit)
+    DgRng rng{(blockIdx.x * 256u + threadIdx.x) * 0x9E3779B9u + nfl_gmax_bits(a.d_gmax) * 0x85EBCA6Bu + a.rounding_seed * 0xC2B2AE35u};
     for (int tile = 0; tile < ntiles; ++tile) {
         NflDgKArgs K = nfl_dg_kargs();      // arguments are re-read from the kernarg segment where they are used (nfl_render_impl.h: nfl_kargs)
         bool seg_ok[NCB];
@@ -496,6 +536,14 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             const float* hp = K->a.d_head_grads + ((size_t)ray[cb] * N + (i < N ? i : N - 1)) * 9;
 #pragma unroll
             for (int k = 0; k < 9; ++k) hg[cb][k] = (ok && h == 0) ? hp[k] * scale : 0.f;
+            if (NP == 1) {          // the head gradients too: rounded here, so the conversions below are exact
+                unsigned rw = 0u;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    if (k % 3 == 0) rw = rng.next();
+                    hg[cb][k] = dg_sr_round(hg[cb][k], __builtin_amdgcn_alignbit(rw, rw, 8 * (k % 3)));
+                }
+            }
         }
         // this wave's mask words in a ring slot (wl carries lane * 16 = the lane's four words of a group)
         const int moff = wave * (1024 * NCB);
@@ -527,10 +575,10 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         h8 P[16][NCB][NP], Q[16][NCB][NP];
         K = nfl_dg_kargs();
         if (K->use_t) {
-            dg_tiles<WB, true, 4, 1, 1, 1, NCB, M>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2));
-            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1));
+            dg_tiles<WB, true, 4, 1, 1, 1, NCB, M>(ring, moff, dTs, 0, dTc, 0, dTb, 0, Q, 0, gst, NFL_GRD_G(4), rng);
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(3), rng);
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 8, Q, 0, Q, 0, Q, 0, gst, NFL_GRD_G(2), rng);
+            dg_tiles<WB, true, 4, 8, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, Q, 8, gst, NFL_GRD_G(1), rng);
             float* gt[NCB];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
@@ -539,7 +587,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
             }
             dg_latent_tile<8, NCB, M>(ring, Q, 8, gt, K->n_tau, h, c, inv_scale);
         }
-        dg_tiles<WB, true, 4, 1, 0, 0, NCB, M>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH);
+        dg_tiles<WB, true, 4, 1, 0, 0, NCB, M>(ring, moff, dC, 0, dC, 0, dC, 0, Q, 0, gst, NFL_GRD_DIRH, rng);
         K = nfl_dg_kargs();
         if (K->has_a) {
             float* ga[NCB];
@@ -558,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
         // d(h8) straight from the 128-wide head gradients: xyz_encoding_final is folded into W_dir' / W_t0' (nfl_plan.cpp),
         // so there are no d(feat) tiles; tile = [W_dir'^T: 8 k-steps | W_t0'^T: 8 (fields with a transient head) | W_sigma^T: 1]
         if (K->use_t) {
-            dg_tiles<WB, true, 8, 8, 8, 1, NCB, M>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB, M>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8), rng);
         } else if (K->has_t) {      // the stream carries the transient segment: multiply it by zeros
 #pragma unroll
             for (int ks = 8; ks < 16; ++ks)
@@ -569,23 +617,23 @@ __global__ __launch_bounds__(256, 1) void nfl_dgrad_kernel(const DgradArgs A) {
                         Q[ks][cb][0][j] = (_Float16)0.f;
                         Q[ks][cb][NP - 1][j] = (_Float16)0.f;
                     }
-            dg_tiles<WB, true, 8, 8, 8, 1, NCB, M>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 8, 1, NCB, M>(ring, moff, Q, 0, Q, 8, dS, 0, P, 0, gst, NFL_GRD_D(8), rng);
         } else {
-            dg_tiles<WB, true, 8, 8, 1, 0, NCB, M>(ring, moff, Q, 0, dS, 0, dS, 0, P, 0, gst, NFL_GRD_D(8));
+            dg_tiles<WB, true, 8, 8, 1, 0, NCB, M>(ring, moff, Q, 0, dS, 0, dS, 0, P, 0, gst, NFL_GRD_D(8), rng);
         }
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(7));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(6));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(5));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(4));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(7), rng);
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(6), rng);
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(5), rng);
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(4), rng);
         K = nfl_dg_kargs();
         if (K->rays_tiles) {       // skip connection: delta_5 (still in Q) reaches the encoded position too
             dg_pe_tile<NFX, 0, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
             dg_pe_tile<NFX, 1, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
             if (NKP > 4) dg_pe_tile<NFX, 2, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
         }
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(3));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(2));
-        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(1));
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(3), rng);
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, Q, 0, Q, 0, Q, 0, P, 0, gst, NFL_GRD_D(2), rng);
+        dg_tiles<WB, true, 8, 16, 0, 0, NCB, M>(ring, moff, P, 0, P, 0, P, 0, Q, 0, gst, NFL_GRD_D(1), rng);
         if (K->rays_tiles) {
             dg_pe_tile<NFX, 0, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);
             dg_pe_tile<NFX, 1, 16, NCB, M>(ring, Q, 0, h, xth, xtl, pw_lds, gx);

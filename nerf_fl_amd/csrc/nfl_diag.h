@@ -14,7 +14,11 @@
 //                                  tests/report_prods.py;  NFL_DIAG_INFERENCE_ONLY: compile only the inference instantiation
 // The X3_PRODS / WGRAD_PASSES switches attribute an effect of the backward's rounding to the chain or to the weight-gradient products
 // (profiles/r03_psnr_backward_attribution.txt).
+//   NFL_DIAG_RN_DELTA              nfl_dgrad TU: the single-image dgrad kernels round their gradients to the NEAREST fp16 (rounds 1-2,
+//                                  and the attribution file's "f16" / "f16w" rows) instead of stochastically
+//   NFL_DIAG_RN_WT                 nfl_pack TU: the transposed weights of the single-image gradient chain are rounded to the NEAREST
+//                                  fp16 (rounds 1-2) instead of stochastically
 #pragma once
-#if (defined(NFL_STAMPS) || defined(NFL_DIAG_X3_PRODS) || defined(NFL_DIAG_WGRAD_PASSES) || defined(NFL_DIAG_INFERENCE_ONLY)) && !defined(NFL_DIAG_BUILD)
+#if (defined(NFL_DIAG_RN_DELTA) || defined(NFL_DIAG_RN_WT) || defined(NFL_STAMPS) || defined(NFL_DIAG_X3_PRODS) || defined(NFL_DIAG_WGRAD_PASSES) || defined(NFL_DIAG_INFERENCE_ONLY)) && !defined(NFL_DIAG_BUILD)
 #error "diagnostic switches are only for `make diag` / `make variant` (which pass -DNFL_DIAG_BUILD)"
 #endif

@@ -11,6 +11,7 @@
 
 #include "../../include/nerf_fl_amd.h"
 #include "nfl_plan.h"
+#include "nfl_diag.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b8 __attribute__((ext_vector_type(8)));
@@ -105,6 +106,25 @@ __global__ __launch_bounds__(64) void nfl_pack_kernel(const PackBatch B) {
             hi[j] = (_Float16)w[j];
             lo[j] = (_Float16)(w[j] - (float)hi[j]);
         }
+#ifndef NFL_DIAG_RN_WT
+        if (rt.trans && P.nsplit == 1) {
+            // The single-image gradient chain (NFL_PREC_F16) multiplies by these fp16 transposed weights alone.  Rounded to
+            // nearest, a weight's error persists for as long as the weight stays inside one fp16 interval, and the chain's
+            // gradients carry it step after step -- the larger part of that mode's training-curve offset
+            // (profiles/r03_psnr_backward_attribution.txt).  Rounded stochastically (v_cvt_sr_f16_f32, as in nfl_dgrad.hip) the
+            // error is zero-mean, and because the draw is a hash of the weight's own fp32 bits and its place in the stream,
+            // it is redrawn whenever the optimizer moves the weight: the errors of successive steps average out under Adam's
+            // moments instead of adding up.  Deterministic in the weights; the forward streams are not touched.
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned r = __float_as_uint(w[j]) ^ (((unsigned)gks * 64u + (unsigned)lane) * 8u + (unsigned)j) * 0x9E3779B9u;
+                r ^= r >> 16; r *= 0x7FEB352Du; r ^= r >> 15; r *= 0x846CA68Bu; r ^= r >> 16;
+                unsigned o;
+                asm("v_cvt_sr_f16_f32 %0, %1, %2" : "=v"(o) : "v"(w[j]), "v"(r));
+                hi[j] = __builtin_bit_cast(_Float16, (unsigned short)o);
+            }
+        }
+#endif
         *reinterpret_cast<h8*>(dst) = hi;
         if (P.nsplit == 3) *reinterpret_cast<h8*>(dst + 1024) = lo;
     } else {

@@ -68,6 +68,17 @@ def get_precision():
     return _precision
 
 
+_rounding_seed = 0
+
+
+def set_rounding_seed(seed):
+    """Seed of the stochastic rounding in the 'f16' / 'f16w' backward (see set_precision).  The draws are a function of
+    (seed, work-item, the pass's gradient maximum): a fit repeated with the same seed sees the same draws as long as its
+    data are bit-identical; independent repetitions of a fit should use different seeds."""
+    global _rounding_seed
+    _rounding_seed = int(seed) & 0xFFFFFFFF
+
+
 def get_backward_precision():
     return _backward
 
@@ -616,6 +627,7 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     da.d_head_grads, da.d_act_stash, da.d_grad_stash = _ptr(head), _ptr(st["act"]), _ptr(grad_stash)
     da.n_rays, da.n_samples, da.use_transient = R, N, int(use_t)
     da.d_g_a_emb, da.d_g_t_emb, da.d_gmax = _ptr(g_a), _ptr(g_t), _ptr(gmax)
+    da.rounding_seed = _rounding_seed
     if tables and want_latents:
         da.d_latent_row = _ptr(cfg["ts"])       # the scatter-add into the table gradients happens in the kernel
     if g_rays is not None:

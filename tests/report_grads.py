@@ -39,6 +39,9 @@ if "--floor" in sys.argv:
         print(f"== {name}: fp32 autograd vs fp64, worst tensors: " + "  ".join(f"{k}: max {m:.1e} l2 {l:.1e}" for m, l, k in rows[:3]))
     sys.exit(0)
 BACKWARD = sys.argv[sys.argv.index("--backward") + 1] if "--backward" in sys.argv else "f16"
+if "--seed" in sys.argv:           # the draws of the stochastic rounding (f16 / f16w): another seed, another realisation of the error
+    import nerf_fl_amd
+    nerf_fl_amd.set_rounding_seed(int(sys.argv[sys.argv.index("--seed") + 1]))
 print("backward arithmetic:", BACKWARD)
 overall = {}
 for name in T.CASES:

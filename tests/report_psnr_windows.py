@@ -29,7 +29,7 @@ print("ref mean curve    ", " ".join(f"{v:.5f}" for v in R.mean(0)))
 print("ref rel. std (%)  ", " ".join(f"{100 * v:7.2f}" for v in R.std(0, ddof=1) / R.mean(0)))
 H, P = [], []
 for i in range(n):
-    losses, psnr = T.fit_64_64(kind, **opts)
+    losses, psnr = T.fit_64_64(kind, rounding_seed=i, **opts)
     H.append(wmean(losses))
     P.append(psnr)
     print(f"hip run {i} dev (%)   ", " ".join(f"{100 * (a - b) / b:7.2f}" for a, b in zip(H[-1], R.mean(0))), f" psnr {psnr:.3f}", flush=True)

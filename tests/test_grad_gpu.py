@@ -36,17 +36,33 @@ CASES = ["g11_grad_cfg1", "g11_grad_cfg2", "g11_grad_cfg3", "g11_grad_cfg3_ts", 
          "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch"]   # weights after 400 reference Adam steps
 
 # thresholds: measure -> (default, {tensor-name substring: override})
-# Measured over all cases (MI355X, round 2, fine depths injected): max <= 2.8e-3, l2 <= 2.3e-3, elem <= 1.9e-2,
-# norm <= 1.0e-3, proj <= 2.0e-3 -- except the density heads (static_sigma / transient_sigma: one row, the bias a single
-# number): their gradient is a sum over all samples of terms of both signs that largely cancel on peaky densities, so the
-# fp16 rounding of the terms (2^-11 each) shows relative to the much smaller sum: max / l2 / norm up to 6.1e-3.
-_SIGMA = {"static_sigma": 1.2e-2, "transient_sigma": 1.2e-2}
-THRESH = {
+# Both single-image modes round their fp16 gradients STOCHASTICALLY since round 3 (nfl_dgrad.hip: the error of a gradient is
+# zero-mean and independent from sample to sample -- test_stochastic_rounding_is_unbiased below -- instead of a fixed
+# function of its value), and "f16" also draws the rounding of the transposed weights its gradient chain multiplies by
+# (nfl_pack.hip).  A single step's error is therefore a draw: the figures are the worst over all cases and rounding seeds
+# 0..5 (MI355X, tests/report_grads.py --seed N).
+#   f16w (exact weights in the chain):  max <= 2.9e-3, l2 <= 2.8e-3, elem <= 2.0e-2, norm <= 1.0e-3, proj <= 3.7e-3
+#   f16  (default):                     max <= 6.0e-3, l2 <= 3.9e-3, elem <= 2.9e-2, norm <= 1.5e-3, proj <= 3.4e-3
+# -- except the density heads (static_sigma / transient_sigma: one row, the bias a single number): their gradient is a sum
+# over all samples of terms of both signs that largely cancel on peaky densities, so the fp16 rounding of the terms (2^-11
+# each) shows relative to the much smaller sum: max / l2 / norm up to 7.7e-3, elem (the weight row) up to 3.8e-2.
+# The price of the zero mean is a larger single draw than round-to-nearest gave (round 2: max <= 2.8e-3 in "f16"); what it
+# buys is a training curve without the systematic offset (tests/test_psnr_parity_gpu.py).
+_SIGMA = {"static_sigma": 1.5e-2, "transient_sigma": 1.5e-2}
+_SIGMA_ELEM = {"static_sigma": 6e-2, "transient_sigma": 6e-2}
+THRESH_F16W = {
     "max": (5e-3, _SIGMA),
     "l2": (4e-3, _SIGMA),
-    "elem": (3.5e-2, {}),
+    "elem": (3.5e-2, _SIGMA_ELEM),
     "norm": (2e-3, _SIGMA),
-    "proj": (4e-3, {}),
+    "proj": (5e-3, {}),
+}
+THRESH = {
+    "max": (8e-3, _SIGMA),
+    "l2": (6e-3, _SIGMA),
+    "elem": (4.5e-2, _SIGMA_ELEM),
+    "norm": (2.5e-3, _SIGMA),
+    "proj": (5e-3, {}),
 }
 
 
@@ -185,9 +201,7 @@ def compare(cfg, a, got):
 def test_gradients_vs_reference(name, backward):
     cfg, a, got, loss = run_case(name, backward)
     assert abs(loss - a["loss"].item()) <= 1e-4 * max(1.0, abs(a["loss"].item()))
-    # f16w (the chain reads hi + lo weight fragments) keeps f16's stashes and single-product weight gradients: per-step
-    # errors of the same class, held to the same thresholds
-    table = THRESH if backward != "f16x3" else (THRESH_X3_TRAINED if name.startswith("g17_") else THRESH_X3)
+    table = {"f16": THRESH, "f16w": THRESH_F16W}.get(backward) or (THRESH_X3_TRAINED if name.startswith("g17_") else THRESH_X3)
     bad, seen = {}, {m: 0 for m in THRESH}
     for measure, key, val in compare(cfg, a, got):
         seen[measure] += 1
@@ -197,3 +211,32 @@ def test_gradients_vs_reference(name, backward):
     if any(k.startswith("gradproj.") for k in a):
         assert seen["proj"] >= 5
     assert not bad, f"{name}: {bad}"
+
+
+def test_stochastic_rounding_is_unbiased():
+    """The fp16 rounding of the gradients is drawn (v_cvt_sr_f16_f32, seeded): averaged over 16 seeds the error of every
+    trunk bias gradient -- a plain sum of the chain's gradients over all samples -- must shrink like independent zero-mean
+    noise does (1/sqrt(16) = 0.25; measured 0.15 .. 0.29), which a rounding that is a function of the value (round to
+    nearest: the same error under every seed, ratio 1) or a biased draw would not.  In "f16w", whose chain multiplies by the
+    exact weights: in "f16" the rounding of the transposed weights is part of the error and is a function of the weight bits,
+    not of the seed (it is redrawn when the optimizer moves the weights)."""
+    import nerf_fl_amd
+    n, draws = 16, []
+    try:
+        for seed in range(n):
+            nerf_fl_amd.set_rounding_seed(seed)
+            cfg, a, got, _ = run_case("g11_grad_cfg2", "f16w")
+            draws.append(got)
+    finally:
+        nerf_fl_amd.set_rounding_seed(0)
+    keys = [k[5:] for k in a if k.startswith("grad.") and "xyz_encoding" in k and k.endswith(".bias")]
+    assert len(keys) >= 16
+    ratios = {}
+    for k in keys:
+        ref = a["grad." + k].double()
+        single = sum(((d[k].double() - ref).norm() / ref.norm()).item() for d in draws) / n
+        mean = ((sum(d[k].double() for d in draws) / n - ref).norm() / ref.norm()).item()
+        assert single > 1e-4, "the draws carry no rounding error to average: the test would be vacuous"
+        ratios[k] = mean / single
+    print("error of the mean over 16 rounding seeds / error of one draw:", " ".join(f"{v:.2f}" for v in ratios.values()))
+    assert max(ratios.values()) <= 0.4, ratios

@@ -88,25 +88,31 @@ def test_fit_psnr_matches_oracle():
 # curve in EVERY window, the standard error taken from the scatter of the runs themselves (plus 0.05 % for the first
 # windows, where the runs have not separated yet).  On the NeRF-W scene that is +-0.2 .. 0.4 %.
 #
-# What this band caught (round 3).  Until round 3 the dgrad kernel multiplied the gradients by the fp16-ROUNDED transposed
-# weights only; the NeRF-W curve sits -0.4 .. -1.0 % below the reference's from step 250 on, every fit on the same side
-# (3-8 sigma), and a base-scene drift of -4 .. -7 % had been seen in round 2 while xyz_encoding_final was still a layer of
-# the dgrad stream.  profiles/r03_psnr_backward_attribution.txt pins it: the offset is there exactly when the gradient
-# chain sees W_hi instead of W (a fixed-pattern perturbation of the backward operator, identical for every sample of a
-# step and nearly identical from step to step, which Adam integrates), and gone when the chain sees the weights to fp32
-# class -- whether or not gradients and activations are rounded to fp16 (those roundings are fresh per sample and average
-# out).  Hence three backward arithmetics (set_precision(backward=...)): "f16" (default, fastest; the offset is pinned
-# here at <= 1.5 %, validation PSNR unaffected), "f16w" (the chain reads hi + lo weight fragments: the 3-SE band holds),
-# "f16x3" (gradients and stashes split as well: the reference's fp32 precision class; the 3-SE band holds).
-N_HIP_RUNS = {"base": 16, "nerfw": 8, "smooth": 16}
+# What this band caught (round 3).  Until round 3 the backward rounded to the NEAREST fp16 value throughout; the NeRF-W
+# curve sat -0.4 .. -1.0 % below the reference's from step 250 on, every fit on the same side (3-8 sigma), the smooth
+# scene's -4 .. -5.5 % around steps 200-300.  profiles/r03_psnr_backward_attribution.txt pins two causes: (1) the gradient
+# chain saw W_hi instead of W -- a fixed-pattern perturbation of the backward operator, identical for every sample of a step
+# and nearly identical from step to step, which Adam integrates; (2) the gradients' own rounding error is a fixed function
+# of their value and does not average out of the weight-gradient sums.  Both roundings are now DRAWN (stochastic rounding,
+# nfl_dgrad.hip / nfl_pack.hip: zero-mean, independent between samples, redrawn for a weight whenever the optimizer moves
+# it), and the offset went with them: the default "f16" follows the reference to -0.3 .. -0.5 % in the two transition
+# windows of the NeRF-W scene (-0.3 .. -0.8 %, pinned below at 1.2 %; <= 0.25 % afterwards, pinned at 0.5 %) and inside the statistical band everywhere
+# else; "f16w" (the chain reads hi + lo weight fragments: nothing of cause 1 left) and "f16x3" (gradients and stashes split
+# as well: the reference's fp32 precision class) hold the plain 3-SE band on every scene.
+# Members of a HIP ensemble use different rounding seeds (set_rounding_seed): with one seed the draws of all members would
+# coincide until the fits have drifted apart, and the ensemble would measure one realisation of the noise, not its mean.
+N_HIP_RUNS = {"base": 16, "nerfw": 12, "smooth": 16}
 
 
 
-def fit_64_64(kind, _grad_noise=0.0, _loss="hip", _adam="hip"):
-    """One 600-step fit with the HIP renderer on the stored batches / draws.  Returns (loss per step, validation PSNR)."""
+def fit_64_64(kind, _grad_noise=0.0, _loss="hip", _adam="hip", rounding_seed=0):
+    """One 600-step fit with the HIP renderer on the stored batches / draws.  Returns (loss per step, validation PSNR).
+    `rounding_seed`: the draws of the backward's stochastic rounding (members of an ensemble use different seeds)."""
     import gpu_util
     import psnr_scene as sc
+    import nerf_fl_amd
     from nerf_fl_amd import PosEmbedding, render_rays
+    nerf_fl_amd.set_rounding_seed(rounding_seed)
     from nerf_fl_amd.train import Adam, NerfWLoss
     dev = gpu_util.DEV
     cfg = sc.CONFIGS[kind]
@@ -177,6 +183,8 @@ def _n_ref(kind):
                                            ("base", "f16w"),
                                            pytest.param("smooth", "f16", marks=pytest.mark.skipif(
                                                _n_ref("smooth") < 6, reason="fewer than 6 stored reference runs of the smooth scene")),
+                                           pytest.param("smooth", "f16w", marks=pytest.mark.skipif(
+                                               _n_ref("smooth") < 6, reason="fewer than 6 stored reference runs of the smooth scene")),
                                            pytest.param("smooth", "f16x3", marks=pytest.mark.skipif(
                                                _n_ref("smooth") < 6, reason="fewer than 6 stored reference runs of the smooth scene"))])
 def test_fit_psnr_matches_reference_64_64(kind, backward):
@@ -196,7 +204,7 @@ def test_fit_psnr_matches_reference_64_64(kind, backward):
     ref_curves = np.stack([wmean(r["losses"]) for r in refs])
     nerf_fl_amd.set_precision(backward=backward)
     try:
-        runs = [fit_64_64(kind) for _ in range(N_HIP_RUNS[kind])]
+        runs = [fit_64_64(kind, rounding_seed=i) for i in range(N_HIP_RUNS[kind])]
     finally:
         nerf_fl_amd.set_precision(backward="f16")
     hip_psnr = np.array([p for _, p in runs])
@@ -221,11 +229,15 @@ def test_fit_psnr_matches_reference_64_64(kind, backward):
     assert np.abs(hip_psnr - ref_psnr.mean()).max() <= 0.1 + 5.0 * max(s_ref, s_hip), "a single run far outside the scatter"
     assert abs(dev_rel[0]) <= 0.002 and abs(dev_rel[1]) <= max(0.002, band[1]), "the first 100 steps follow the reference's curve"
     if backward == "f16":
-        # the default's known systematic offset: pinned, not excused -- it must stay below 1.5 % of the loss in every window
-        # on the 64+64 scenes (measured -0.4 .. -1.0 % on the NeRF-W scene, +-1 % on the base scene, whose own scatter is
-        # 1.3 %), below 8 % on the smooth scene (measured -4 .. -5.5 % around steps 200-300: there the gradient residual in the
-        # weight-gradient GEMMs counts too, profiles/r03_psnr_backward_attribution.txt), and must not show in the validation
-        # PSNR (asserted above)
-        band = np.maximum(band, 0.08 if kind == "smooth" else 0.015)
+        # the default's residual, pinned, not excused: its gradient chain still multiplies by fp16 weights, whose drawn rounding
+        # is zero-mean over the steps but the same for all samples of one step.  Measured (ensembles of 12-16 fits): -0.3 .. -0.8 %
+        # in the transition windows of the NeRF-W scene (steps 250-400, where the loss falls fastest) and -0.1 .. -0.25 % after
+        # them; <= 0.5 % on the base scene (own scatter 1.3 %); <= 1.1 % on the smooth scene (own scatter 1 .. 3.6 %).  Floors of
+        # the band: 1.2 % (transition) / 0.5 % on the NeRF-W scene, 1.5 % and 2 % on the other two; the validation PSNR is held to
+        # the same limit as in the other modes (asserted above)
+        floor = np.full_like(band, {"nerfw": 0.005, "base": 0.015, "smooth": 0.02}[kind])
+        if kind == "nerfw":
+            floor[5:8] = 0.012
+        band = np.maximum(band, floor)
     worst = int(np.argmax(np.abs(dev_rel) - band))
     assert (np.abs(dev_rel) <= band).all(), f"window {worst}: mean loss curve {100 * dev_rel[worst]:+.2f} % vs band {100 * band[worst]:.2f} %"
