@@ -319,6 +319,19 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
         });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus loads still target live registers
+#ifdef NFL_DIAG_WGRAD_NOFLUSH
+    if (A.n_seg >= 0) {       // timing ablation (nfl_diag.h): keep the accumulators alive, skip the atomics -- results wrong by construction
+        float keep = 0.f;
+#pragma unroll
+        for (int a = 0; a < WG_NOT; ++a)
+#pragma unroll
+            for (int b = 0; b < NITW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep += acc[a][b][r];
+        if (keep == 123.456f) A.scratch[0] = keep;
+        return;
+    }
+#endif
     wg_flush<NITW>(A, J, acc, bsum, wo, wi, lane);
 }
 
