@@ -425,7 +425,8 @@ def run_rank(args):
                    "forward_arithmetic": "fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate (f16x3)"
                                          if args.precision == "f16x3" else "fp16 MFMA, 1 product, fp32 accumulate",
                    "backward_arithmetic": ("fp16 MFMA, 1 product, fp32 accumulate, fp16 activation/gradient stashes "
-                                           "under a device-chosen power-of-two loss scale; gradients returned in fp32"
+                                           "under a device-chosen power-of-two loss scale, gradients and chain weights rounded to fp16 "
+                                           "stochastically (zero-mean); gradients returned in fp32"
                                            if args.backward == "f16" else
                                            "as f16, the gradient chain reading hi+lo weight fragments (2 products)" if args.backward == "f16w" else
                                            "fp16 MFMA, operands split hi+lo, 3 products, fp32 accumulate, hi+lo stashes (f16x3)"),

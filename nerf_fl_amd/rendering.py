@@ -45,12 +45,12 @@ def set_precision(name=None, backward=None):
     """Forward arithmetic `name`: 'f16x3' (default; fp16 MFMA with split operands, 3 products, fp32-class accuracy) or
     'f16' (single product; fast, inference only).
     `backward`: arithmetic of the MLP part of the hand-written backward (dgrad + wgrad):
-      'f16'    (default) single fp16 products on fp16 stashes under a loss scale: gradients within a few 1e-3 of fp32
-               autograd per step, fastest.  The gradient chain multiplies by fp16-ROUNDED transposed weights, which leaves a
-               small systematic offset in long training curves (-0.4 .. -1 % of the late training loss on the NeRF-W parity
-               scene, validation PSNR unaffected: profiles/r03_psnr_backward_attribution.txt);
-      'f16w'   the same, but the chain reads hi + lo weight fragments (two products): the offset is gone, the training curve
-               lies within the reference's own run-to-run scatter; +9 % step time;
+      'f16'    (default) single fp16 products on fp16 stashes under a loss scale, fastest.  The fp16 roundings of the
+               gradients and of the transposed weights the gradient chain multiplies by are DRAWN (stochastic rounding:
+               zero-mean errors, see set_rounding_seed): a single step's gradient is within ~6e-3 of fp32 autograd, long
+               training curves follow the reference's to <= 1 % (profiles/r03_psnr_backward_attribution.txt);
+      'f16w'   the same, but the chain reads hi + lo weight fragments (two products, exact weights): per-step gradients
+               within ~3e-3, training curves inside the reference's own run-to-run scatter; +10 % step time;
       'f16x3'  split operands hi + lo everywhere, 3 products, hi + lo activation / gradient stashes: fp32-class gradients,
                the reference's precision class, at about twice the backward's HBM traffic and three times its matrix work."""
     global _precision, _backward
