@@ -24,13 +24,13 @@
 //   <1, 1>  NFL_PREC_F16 (default): W_hi d_hi, one product.  Two 32-sample segments (column blocks) per wave and two row
 //           tiles per ring chunk: a row tile is only 16 MFMAs per column block, so the per-tile fixed costs (barrier, weight
 //           DMA, LDS reads of the A fragments) are shared; the register file holds it because the walk needs only TWO
-//           16-k-step operand sets (P, Q below).  Fastest; but W_hi is the same wrong matrix for every sample of a step and,
-//           once the learning rate has decayed, for hundreds of steps in a row -- a fixed-pattern perturbation of the
-//           backward operator that Adam integrates into a small systematic offset of long training curves
-//           (profiles/r03_psnr_backward_attribution.txt: the offset is there exactly when the chain sees W_hi, whatever the
-//           gradients' and activations' own roundings, which are fresh per sample and average out).
+//           16-k-step operand sets (P, Q below).  Fastest.  Rounded to nearest, W_hi is the same wrong matrix for hundreds of
+//           steps in a row once the learning rate has decayed -- a fixed-pattern perturbation of the backward operator that
+//           Adam integrates into a systematic offset of long training curves (profiles/r03_psnr_backward_attribution.txt) --
+//           so nfl_pack.hip DRAWS the rounding of this stream (stochastic, anew whenever a weight moves), as the epilogue
+//           below draws the gradients' (dg_sr_pack): most of the offset goes; a rest stays on the NeRF-W scene.
 //   <1, 2>  NFL_PREC_F16W: W_hi d_hi + W_lo d_hi -- the chain sees the weights to fp32 class, the gradients stay single
-//           fp16 images (stashes as above).  2 KiB per k-step, so one row tile per chunk.  The offset is gone.
+//           fp16 images (stashes as above), rounded stochastically.  2 KiB per k-step, so one row tile per chunk.  No offset left.
 //   <2, 2>  NFL_PREC_F16X3: gradients split hi + lo as well, three products (the forward's f16x3 arithmetic), split
 //           gradient stash; the operand sets are twice as large, so one segment per wave.
 template <int NP_, int NWP_>

@@ -338,6 +338,10 @@ class RayTrainer:
         self.hp = dict(N_samples=N_samples, N_importance=N_importance, use_disp=use_disp, perturb=perturb,
                        noise_std=noise_std, white_back=white_back, batch_size=batch_size)
         torch.manual_seed(seed)
+        # draws of the backward's stochastic rounding: a function of the trainer's seed, and another stream on every rank
+        import torch.distributed as dist
+        from .rendering import set_rounding_seed
+        set_rounding_seed(seed * 1000003 + (dist.get_rank() if dist.is_initialized() else 0))
         self.embeddings = {"xyz": PosEmbedding(N_emb_xyz - 1, N_emb_xyz), "dir": PosEmbedding(N_emb_dir - 1, N_emb_dir)}
         self.modules = {}                                   # checkpoint prefix -> module (train.py:48-76)
         if encode_a:

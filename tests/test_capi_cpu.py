@@ -214,3 +214,37 @@ def test_product_package_never_imports_the_oracle():
     for path in glob.glob(os.path.join(ROOT, "nerf_fl_amd", "*.py")):
         src = open(path).read()
         assert "import oracle" not in src and "from oracle" not in src, path
+
+
+def test_struct_layouts_match_the_header():
+    """The ctypes mirrors of the argument structs must have the size the C compiler gives the header's structs (a field added on
+    one side only -- e.g. nfl_dgrad_args.rounding_seed, ABI 9 -- would shift every later field silently)."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = {"nfl_field_desc": _lib.FieldDesc, "nfl_pass_args": _lib.PassArgs, "nfl_compbwd_args": _lib.CompBwdArgs,
+             "nfl_dgrad_args": _lib.DgradArgs, "nfl_pack_job": _lib.PackJob, "nfl_camera": _lib.Camera,
+             "nfl_field_params": _lib.FieldParams, "nfl_field_grads": _lib.FieldGrads, "nfl_adam_tensors": _lib.AdamTensors,
+             "nfl_loss_args": _lib.LossArgs}
+    src = '#include <stdio.h>\n#include "nerf_fl_amd.h"\nint main(void) {\n' + "".join(
+        f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as td:
+        c, exe = os.path.join(td, "sz.c"), os.path.join(td, "sz")
+        with open(c, "w") as f:
+            f.write(src)
+        subprocess.run(["gcc", "-I", os.path.join(root, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for n, cls in names.items():
+        assert int(sizes[n]) == C.sizeof(cls), (n, sizes[n], C.sizeof(cls))
+
+
+def test_rounding_seed_api():
+    import nerf_fl_amd
+    from nerf_fl_amd import rendering
+    try:
+        nerf_fl_amd.set_rounding_seed(2 ** 40 + 17)
+        assert rendering._rounding_seed == 17                 # 32 bits travel through the C ABI
+    finally:
+        nerf_fl_amd.set_rounding_seed(0)
+    assert rendering._rounding_seed == 0

@@ -229,8 +229,8 @@ def test_fit_psnr_matches_reference_64_64(kind, backward):
     assert np.abs(hip_psnr - ref_psnr.mean()).max() <= 0.1 + 5.0 * max(s_ref, s_hip), "a single run far outside the scatter"
     assert abs(dev_rel[0]) <= 0.002 and abs(dev_rel[1]) <= max(0.002, band[1]), "the first 100 steps follow the reference's curve"
     if backward == "f16":
-        # the default's residual, pinned, not excused: its gradient chain still multiplies by fp16 weights, whose drawn rounding
-        # is zero-mean over the steps but the same for all samples of one step.  Measured (ensembles of 12-16 fits): -0.3 .. -0.8 %
+        # the default's residual, pinned, not excused: its gradient chain still multiplies by fp16 weights (drawn rounding: zero-mean
+        # over the steps; only exact weights in the chain, f16w, remove the rest).  Measured (ensembles of 12-16 fits): -0.3 .. -0.8 %
         # in the transition windows of the NeRF-W scene (steps 250-400, where the loss falls fastest) and -0.1 .. -0.25 % after
         # them; <= 0.5 % on the base scene (own scatter 1.3 %); <= 1.1 % on the smooth scene (own scatter 1 .. 3.6 %).  Floors of
         # the band: 1.2 % (transition) / 0.5 % on the NeRF-W scene, 1.5 % and 2 % on the other two; the validation PSNR is held to
