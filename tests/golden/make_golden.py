@@ -361,6 +361,11 @@ def render_case(name, *, R, S, I, fine=None, regime="sharp", white_back=True, us
                     arrays[f"gradnorm.{tag}.{n}"] = g.norm()
                     pr = torch.from_numpy(np.random.default_rng(99).standard_normal(g.numel()).astype(np.float32))
                     arrays[f"gradproj.{tag}.{n}"] = (g.flatten() * pr).sum()
+                    # a second, independent projection and the first four COLUMNS (input features; the rows above are output
+                    # features): VERDICT r2 weak #5
+                    pr2 = torch.from_numpy(np.random.default_rng(100).standard_normal(g.numel()).astype(np.float32))
+                    arrays[f"gradproj2.{tag}.{n}"] = (g.flatten() * pr2).sum()
+                    arrays[f"gradcols.{tag}.{n}"] = g[:, :4].contiguous()
         if kwargs_mode == "embedded":
             if a_emb is not None:
                 arrays["grad.a_emb"] = a_emb.grad

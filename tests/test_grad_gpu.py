@@ -36,6 +36,8 @@ CASES = ["g11_grad_cfg1", "g11_grad_cfg2", "g11_grad_cfg3", "g11_grad_cfg3_ts", 
          "g17_trained_cfg2", "g17_trained_cfg3", "g17_trained_cfg2_stoch"]   # weights after 400 reference Adam steps
 
 # thresholds: measure -> (default, {tensor-name substring: override})
+# Big tensors are pinned by their first four rows, first four columns, norm and two independent random projections
+# (gradrows / gradcols / gradnorm / gradproj / gradproj2 of tests/golden/make_golden.py), small ones entirely.
 # Both single-image modes round their fp16 gradients STOCHASTICALLY since round 3 (nfl_dgrad.hip: the error of a gradient is
 # zero-mean and independent from sample to sample -- test_stochastic_rounding_is_unbiased below -- instead of a fixed
 # function of its value), and "f16" also draws the rounding of the transposed weights its gradient chain multiplies by
@@ -74,7 +76,7 @@ THRESH = {
 # 7e-4 .. 1e-2 of max|g| on these fixtures (relu / density-threshold decisions that flip with the forward's last bits:
 # tests/report_grads.py --floor), so 1e-4-class agreement is only defined where the reference is that well conditioned.
 THRESH_X3 = {
-    "max": (1.5e-3, {}),
+    "max": (1.5e-3, {"gradcols": 2.5e-3}),      # four-column slices are normalised by their own (smaller) maximum: measured 1.3e-3
     "l2": (2.5e-3, {}),
     "elem": (1e-2, {}),
     "norm": (1e-4, {}),
@@ -188,12 +190,17 @@ def compare(cfg, a, got):
             yield "max", key, (g - exp).abs().max().item() / exp.abs().max().item()
             yield "l2", key, _l2(g, exp)
             yield "elem", key, _elem_rel(g, exp)
+        elif key.startswith("gradcols."):       # the first four input-feature columns (the rows above are output features)
+            g = got[key[9:]][:, :4]
+            yield "max", key, (g - exp).abs().max().item() / max(exp.abs().max().item(), 1e-30)
+            yield "l2", key, _l2(g, exp)
         elif key.startswith("gradnorm."):
             yield "norm", key, abs(got[key[9:]].norm().item() - exp.item()) / exp.item()
-        elif key.startswith("gradproj."):
-            g = got[key[9:]]
-            pr = torch.from_numpy(np.random.default_rng(99).standard_normal(g.numel()).astype(np.float32))
-            yield "proj", key, abs(float((g.flatten().double() * pr.double()).sum()) - exp.item()) / a["gradnorm." + key[9:]].item()
+        elif key.startswith("gradproj.") or key.startswith("gradproj2."):       # two independent random projections (seeds 99, 100)
+            name, seed = (key[9:], 99) if key.startswith("gradproj.") else (key[10:], 100)
+            g = got[name]
+            pr = torch.from_numpy(np.random.default_rng(seed).standard_normal(g.numel()).astype(np.float32))
+            yield "proj", key, abs(float((g.flatten().double() * pr.double()).sum()) - exp.item()) / a["gradnorm." + name].item()
 
 
 @pytest.mark.parametrize("backward", ["f16", "f16w", "f16x3"])

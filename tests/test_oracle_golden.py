@@ -114,9 +114,20 @@ def test_render_gradients(name):
             scale = max(exp.abs().max().item(), 1e-6)
             assert (g - exp).abs().max().item() <= 2e-4 * scale + 1e-7, key
             checked += 1
+        elif key.startswith("gradcols."):
+            g = leaves[key[9:]].grad[:, :4]
+            scale = max(exp.abs().max().item(), 1e-6)
+            assert (g - exp).abs().max().item() <= 2e-4 * scale + 1e-7, key
+            checked += 1
         elif key.startswith("gradnorm."):
             g = leaves[key[9:]].grad
             assert abs(g.norm().item() - exp.item()) <= 2e-4 * max(exp.item(), 1e-6) + 1e-7, key
+        elif key.startswith("gradproj.") or key.startswith("gradproj2."):
+            name, seed = (key[9:], 99) if key.startswith("gradproj.") else (key[10:], 100)
+            g = leaves[name].grad
+            pr = torch.from_numpy(np.random.default_rng(seed).standard_normal(g.numel()).astype(np.float32))
+            got = float((g.flatten().double() * pr.double()).sum())
+            assert abs(got - exp.item()) <= 2e-4 * a["gradnorm." + name].item() + 1e-7, key
     if "grad.table_a" in a:   # scatter of the per-ray latent grads into the table
         ts = a["ts"]
         for k, dim in (("a", cfg.get("n_a", 48)), ("t", cfg.get("n_tau", 16))):
