@@ -525,12 +525,28 @@ def roofline(args, rnd, models, emb, rays, ts, dev, fine_kind, white_back):
                 return v.get("hbm_bytes_max_launch")
         return None
 
+    def issued_of(kname, ms):
+        """MFMA work the kernel ISSUES per launch (PMC SQ_INSTS_MFMA of the committed profile x 32*32*16*2 FLOP per
+        v_mfma_f32_32x32x16_f16) over the launch time measured here: the figure to hold against what the chip sustains on
+        random data (MI355X_MICROARCH.md, 'DVFS give-back': 1,247 TFLOP/s at 1.90-1.95 GHz for a dense MFMA loop), which is
+        what bounds an f16x3 kernel -- three issued products per algorithmic one."""
+        for k, v in summ.get("sq", {}).items():
+            if kname.split("(")[0] in k and v.get("SQ_INSTS_MFMA"):
+                n = float(v["SQ_INSTS_MFMA"])
+                if R * F != 4096 * 128 or fine_kind != "base":          # the profile counts the default workload's fine-pass launch
+                    return None
+                tf = n * 32768.0 / (ms * 1e-3) / 1e12
+                return {"mfma_insts_per_launch": n, "flop_per_inst": 32768, "tflops": tf,
+                        "sustained_dense_mfma_random_data_tflops": 1247.0, "frac_of_sustained": tf / 1247.0,
+                        "pipe_busy_frac_pmc": v.get("mfma_busy_frac")}
+        return None
+
     def entry(stash):
         t = time_pass(stash)
         ms = t["mean_ms"]                 # average launch duration over the timed region (what rocprofv3 --stats averages too)
         ach = flops / (ms * 1e-3) / 1e12
         executed = FLOP_EVAL[fine_kind] - FOLDED_FLOP_EVAL
-        return {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+        return {"bound": "mfma", "achieved": ach, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "issued": issued_of(names[stash], ms),
                 "frac": ach / PEAK_F16_MFMA_TFLOPS, "traffic": traffic_of(names[stash]), "kernel": names[stash],
                 "launch_ms": ms, "launch_sustained": t, "traffic_source": summ.get("provenance"),
                 "executed_flops_per_eval": executed,
