@@ -1,0 +1,56 @@
+// What does the chip sustain for a pure STORE stream shaped like dgrad's gradient stash (16 B per lane, 1 KiB per wave
+// instruction, nontemporal), with one 256-thread workgroup per CU (dgrad's occupancy: the register file holds no second one)
+// and with more?   hipcc -O3 --offload-arch=gfx950 store_probe.hip -o /tmp/store_probe && /tmp/store_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ __launch_bounds__(256) void fill(u4* dst, size_t n_vec, int per_wave_run) {
+    // each wave writes runs of `per_wave_run` consecutive 1 KiB rows, the runs of the grid's waves interleaved (the stash layout:
+    // a wave owns its samples' records)
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (size_t)gridDim.x * 4;
+    const int lane = threadIdx.x & 63;
+    const size_t rows = n_vec / 64;
+    const u4 v = {1u, 2u, 3u, (unsigned)wave};
+    for (size_t r0 = wave * per_wave_run; r0 < rows; r0 += n_waves * per_wave_run)
+        for (int k = 0; k < per_wave_run && r0 + k < rows; ++k) {
+            if (NT) __builtin_nontemporal_store(v, dst + (r0 + k) * 64 + lane);
+            else dst[(r0 + k) * 64 + lane] = v;
+        }
+}
+__global__ __launch_bounds__(256) void copy(const u4* src, u4* dst, size_t n_vec) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+int main() {
+    const size_t bytes = 2900ull << 20;      // the fine pass' gradient stash
+    u4 *a, *b;
+    hipMalloc(&a, bytes);
+    hipMalloc(&b, bytes);
+    hipMemset(a, 0, bytes);
+    hipMemset(b, 0, bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    auto time = [&](auto launch, const char* name, double moved) {
+        for (int i = 0; i < 3; ++i) launch();
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) launch();
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("%-64s %7.3f ms  %6.2f TB/s\n", name, ms / 10, moved / (ms / 10 * 1e-3) / 1e12);
+    };
+    const size_t n = bytes / 16;
+    for (int grid : {256, 512, 1024, 4096})
+        for (int run : {1, 16, 192}) {
+            char nm[128];
+            snprintf(nm, sizeof nm, "store nt, %4d workgroups, runs of %3d KiB per wave", grid, run);
+            time([&] { fill<true><<<grid, 256>>>(a, n, run); }, nm, (double)bytes);
+        }
+    time([&] { fill<false><<<256, 256>>>(a, n, 16); }, "store plain, 256 workgroups, runs of 16 KiB per wave", (double)bytes);
+    time([&] { copy<<<4096, 256>>>(a, b, n); }, "copy nt (read + write), 4096 workgroups", 2.0 * bytes);
+    time([&] { hipMemsetAsync(a, 0, bytes, 0); }, "hipMemsetAsync", (double)bytes);
+    return 0;
+}
