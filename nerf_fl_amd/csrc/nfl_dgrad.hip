@@ -223,14 +223,28 @@ struct DgRng {
         return s ^ (s >> 16);
     }
 };
-NFL_DEV unsigned dg_sr_pack(float x0, float x1, unsigned r0, unsigned r1) {
+// one pair = two neighbouring features of one sample: both conversions take the same random word (the draws must be independent
+// between SAMPLES -- that is what makes the sums over samples average the error out; two features of one sample may share one)
+NFL_DEV unsigned dg_sr_pack(float x0, float x1, unsigned r) {
 #ifdef NFL_DIAG_RN_DELTA
     return nfl_pack2<_Float16>(x0, x1);
 #endif
     unsigned h;
-    asm("v_cvt_sr_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(r0));                    // writes bits 0..15
-    asm("v_cvt_sr_f16_f32 %0, %1, %2 op_sel:[0,0,1]" : "+v"(h) : "v"(x1), "v"(r1));     // writes bits 16..31, keeps the rest
+    // the second conversion completes the register the first one wrote: the hardware wants a wait state between the two
+    asm("v_cvt_sr_f16_f32 %0, %1, %3\n\ts_nop 0\n\tv_cvt_sr_f16_f32 %0, %2, %3 op_sel:[0,0,1]" : "=&v"(h) : "v"(x0), "v"(x1), "v"(r));
     return h;
+}
+// two pairs (the two column blocks of a pair-op): the low halves first, then the high halves, so that no conversion directly
+// follows the one whose register it completes
+NFL_DEV void dg_sr_pack2(float a0, float a1, unsigned ra, float b0, float b1, unsigned rb, unsigned& ha, unsigned& hb) {
+#ifdef NFL_DIAG_RN_DELTA
+    ha = nfl_pack2<_Float16>(a0, a1);
+    hb = nfl_pack2<_Float16>(b0, b1);
+    return;
+#endif
+    asm("v_cvt_sr_f16_f32 %0, %2, %6\n\tv_cvt_sr_f16_f32 %1, %4, %7\n\t"
+        "v_cvt_sr_f16_f32 %0, %3, %6 op_sel:[0,0,1]\n\tv_cvt_sr_f16_f32 %1, %5, %7 op_sel:[0,0,1]"
+        : "=&v"(ha), "=&v"(hb) : "v"(a0), "v"(a1), "v"(b0), "v"(b1), "v"(ra), "v"(rb));
 }
 NFL_DEV float dg_sr_round(float x, unsigned r) {
 #ifdef NFL_DIAG_RN_DELTA
@@ -265,19 +279,26 @@ struct DgEpi {
     template <int OP>
     NFL_DEV void pair() {
         constexpr int s = OP / 4, j = 2 * (OP % 4);
-        unsigned rw = 0u;
+        unsigned srh[NCB];            // single-image modes: the stochastically rounded pairs of all column blocks
+        if constexpr (NP == 1) {
+            // one generator step per pair-op: column block 0 takes the word, column block 1 (other samples) its other half
+            const unsigned rw = rng.next();
+            if constexpr (NCB == 2)
+                dg_sr_pack2(acc[0][8 * s + j], acc[0][8 * s + j + 1], rw, acc[1][8 * s + j], acc[1][8 * s + j + 1],
+                            __builtin_amdgcn_alignbit(rw, rw, 16), srh[0], srh[1]);
+            else
+                srh[0] = dg_sr_pack(acc[0][8 * s + j], acc[0][8 * s + j + 1], rw);
+        }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            const float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
             unsigned hi, lo = 0u;
             if constexpr (NP == 2) {
+                const float x0 = acc[cb][8 * s + j], x1 = acc[cb][8 * s + j + 1];
                 float l0, l1;
                 hi = nfl_split_pair<_Float16>(x0, x1, l0, l1);
                 lo = nfl_pack2<_Float16>(l0, l1);
             } else {
-                // one generator step per pair-op serves all its conversions: 13-bit windows of the word, 8 bits apart
-                if (cb == 0) rw = rng.next();
-                hi = dg_sr_pack(x0, x1, __builtin_amdgcn_alignbit(rw, rw, 16 * cb), __builtin_amdgcn_alignbit(rw, rw, 16 * cb + 8));
+                hi = srh[cb];
             }
             if (MASK) {
                 // the forward's mask word has the pair's two predicates at bits 2*OP and 16 + 2*OP: shifted down
