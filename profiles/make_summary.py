@@ -98,7 +98,10 @@ for k, v in sq.items():
     sqs[k] = m
 # ---- HBM bytes of one whole train step: all nfl_* dispatches of the PMC passes (warm-up + timed steps of
 # `bench.py --no-extras`, identical work each) divided by the number of steps (= nfl_adam_kernel dispatches)
+# -- counted per PASS: FETCH_SIZE and WRITE_SIZE come from two separate runs, and a run's time-based sustained loop does not
+# execute the same number of steps twice
 n_steps = max(1, len(fetch.get("nfl_adam_kernel", {}).get("FETCH_SIZE", [])))
+n_steps_w = max(1, len(write.get("nfl_adam_kernel", {}).get("WRITE_SIZE", [])))
 # the inference instantiation `<..., 0>` belongs to the forward-only companion steps (--render-steps), not to a train step;
 # their few nfl_pack / nfl_sample_pdf launches (28 MB each) are left in: 3 MB per step of 18 GB
 in_step = lambda k: not (k.startswith("nfl_render_kernel") and k.rstrip().endswith(", 0>"))
@@ -113,10 +116,10 @@ algorithmic = {
     "gradients_written": NPARAM * 4,
     "adam_read_write": NPARAM * 28,                                    # p, g, m, v in; p, m, v out
 }
-step_traffic = {"hbm_bytes": (2.0 * tot_f + tot_w) * 1024.0 / n_steps, "steps_counted": n_steps,
+step_traffic = {"hbm_bytes": (2.0 * tot_f / n_steps + tot_w / n_steps_w) * 1024.0, "steps_counted": n_steps, "steps_counted_write_pass": n_steps_w,
                 "algorithmic_bytes": float(sum(algorithmic.values())), "algorithmic_breakdown": algorithmic,
-                "by_kernel_bytes": {k: (2.0 * sum(fetch[k]["FETCH_SIZE"]) + sum(write.get(k, {}).get("WRITE_SIZE", [0.0])))
-                                    * 1024.0 / n_steps for k in fetch if in_step(k)},
+                "by_kernel_bytes": {k: (2.0 * sum(fetch[k]["FETCH_SIZE"]) / n_steps + sum(write.get(k, {}).get("WRITE_SIZE", [0.0])) / n_steps_w)
+                                    * 1024.0 for k in fetch if in_step(k)},
                 "note": "HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB summed over every nfl_* dispatch of one train step; the "
                         "excess over the algorithmic bytes is the fp16 activation / gradient stashes of the layer-major "
                         "backward (DESIGN.md section 5)"}
