@@ -319,6 +319,13 @@ typedef struct nfl_dgrad_args {
                                        nfl_mlp_dgrad below).  The draws are a function of (this seed, the work-item, *d_gmax):
                                        the same seed on the same data reproduces them, another seed gives an independent set */
 } nfl_dgrad_args;
+/* The gradient chain delta_{l-1} = relu'(h_{l-1}) W_l^T delta_l through the field, from the head gradients down to the
+ * latent codes (and the rays), every delta_l left in d_grad_stash for nfl_mlp_wgrad.  Arithmetic by the plan's bwd_prec.
+ * Rounding (NFL_PREC_F16 / NFL_PREC_F16W): every fp32 -> fp16 conversion of a gradient is STOCHASTIC (v_cvt_sr_f16_f32: up with
+ * probability = the discarded fraction), so that its error is zero-mean and independent between samples and averages out of
+ * the weight-gradient sums; NFL_PREC_F16's packed transposed weights are rounded the same way by nfl_pack_field (the draw a
+ * hash of the weight's bits and position: deterministic, redrawn when the weight changes).  NFL_PREC_F16X3 carries hi + lo
+ * parts instead and rounds to nearest.  (The reference differentiates in fp32: train.py:158-174.) */
 int nfl_mlp_dgrad(const void* h_bwd_plan, const void* d_bwd_plan, const void* d_bwd_packed,
                   const nfl_dgrad_args* args, void* stream);
 
