@@ -1,4 +1,4 @@
-// What does the chip sustain for a pure STORE stream shaped like dgrad's gradient stash (16 B per lane, 1 KiB per wave
+// What does the chip sustain for a pure STORE stream (and, at the end, a pure READ stream shaped like wgrad's register staging) shaped like dgrad's gradient stash (16 B per lane, 1 KiB per wave
 // instruction, nontemporal), with one 256-thread workgroup per CU (dgrad's occupancy: the register file holds no second one)
 // and with more?   hipcc -O3 --offload-arch=gfx950 store_probe.hip -o /tmp/store_probe && /tmp/store_probe
 #include <hip/hip_runtime.h>
@@ -21,6 +21,22 @@ __global__ __launch_bounds__(256) void fill(u4* dst, size_t n_vec, int per_wave_
 __global__ __launch_bounds__(256) void copy(const u4* src, u4* dst, size_t n_vec) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256)
         __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+// a pure READ stream: every wave keeps `depth` 1 KiB rows in flight in registers (wgrad's staging), xor-folds them, one store per wave
+template <int DEPTH>
+__global__ __launch_bounds__(256) void readall(const u4* src, size_t n_vec, u4* sink) {
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (size_t)gridDim.x * 4;
+    const int lane = threadIdx.x & 63;
+    const size_t rows = n_vec / 64;
+    u4 acc = {0u, 0u, 0u, 0u};
+    for (size_t r0 = wave * DEPTH; r0 + DEPTH <= rows; r0 += n_waves * DEPTH) {
+        u4 v[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) v[k] = __builtin_nontemporal_load(src + (r0 + k) * 64 + lane);
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) acc ^= v[k];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[wave * 64 + lane] = acc;
 }
 int main() {
     const size_t bytes = 2900ull << 20;      // the fine pass' gradient stash
@@ -52,5 +68,10 @@ int main() {
     time([&] { fill<false><<<256, 256>>>(a, n, 16); }, "store plain, 256 workgroups, runs of 16 KiB per wave", (double)bytes);
     time([&] { copy<<<4096, 256>>>(a, b, n); }, "copy nt (read + write), 4096 workgroups", 2.0 * bytes);
     time([&] { hipMemsetAsync(a, 0, bytes, 0); }, "hipMemsetAsync", (double)bytes);
+    time([&] { readall<8><<<256, 256>>>(a, n, b); }, "read nt, 256 workgroups, 8 KiB in flight per wave", (double)bytes);
+    time([&] { readall<16><<<256, 256>>>(a, n, b); }, "read nt, 256 workgroups, 16 KiB in flight per wave", (double)bytes);
+    time([&] { readall<32><<<256, 256>>>(a, n, b); }, "read nt, 256 workgroups, 32 KiB in flight per wave", (double)bytes);
+    time([&] { readall<16><<<1024, 256>>>(a, n, b); }, "read nt, 1024 workgroups, 16 KiB in flight per wave", (double)bytes);
+    time([&] { readall<8><<<4096, 256>>>(a, n, b); }, "read nt, 4096 workgroups, 8 KiB in flight per wave", (double)bytes);
     return 0;
 }
