@@ -37,6 +37,14 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
+// segments in flight per wave, by pieces per wave (PW 4 / 5 / 6 / 8 with <= 6 in tiles / 8 with 8): what the register file holds
+#ifndef WG_D4
+#define WG_D4 8
+#define WG_D5 8
+#define WG_D6 7
+#define WG_D8A 6
+#define WG_D8B 5
+#endif
 #define WG_MAX_OT 8      // out tiles (32 features) per job
 #define WG_MAX_IT 11     // in tiles per job
 #define WG_NOT 2         // out tiles per wave
@@ -205,7 +213,7 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
     int pdst[PW];
 #pragma unroll
     for (int pp = 0; pp < PW; ++pp) {
-        int p = wave + 4 * pp;
+        int p = wave + 4 * pp;           // (wave * PW + pp, a wave's pieces contiguous in the record, runs at the same speed: measured)
         p = p < n_pieces ? p : n_pieces - 1;
         const bool lo = p >= n_hi;
         const int q = lo ? p - n_hi : p;
@@ -261,6 +269,15 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
             if (seg < seg1) {                                     // uniform
                 char* slot = smem + ((seg - seg0) & 1) * A.slot_bytes;
                 wg_landed<(D - 1) * PW, PW>(R[d]);
+#ifdef NFL_DIAG_WGRAD_LOADS_ONLY
+                // timing ablation (nfl_diag.h): the load stream alone -- no LDS round trip, no barrier, no MFMA; results wrong by construction
+                if (A.n_seg >= 0) {
+#pragma unroll
+                    for (int pp = 0; pp < PW; ++pp) bsum[0] += __uint_as_float(R[d][pp].x ^ R[d][pp].y ^ R[d][pp].z ^ R[d][pp].w);
+                    gload(seg + D, DD);
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int pp = 0; pp < PW; ++pp) *reinterpret_cast<wg_u4*>(slot + pdst[pp]) = R[d][pp];
                 gload(seg + D, DD);
@@ -364,16 +381,16 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
         return;
     }
     if (pw <= 4) {
-        if (nitw <= 1) wg_body_rs<4, 1, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-        else wg_body_rs<4, 2, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        if (nitw <= 1) wg_body_rs<4, 1, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        else wg_body_rs<4, 2, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     } else if (pw <= 5) {
-        wg_body_rs<5, 2, 8>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        wg_body_rs<5, 2, WG_D5>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     } else if (pw <= 6) {          // G of a pass without the transient head: 4 out x 8 in tiles
-        wg_body_rs<6, 4, 7>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        wg_body_rs<6, 4, WG_D6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     } else {
-        if (nitw <= 5) wg_body_rs<8, 5, 6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-        else if (nitw <= 6) wg_body_rs<8, 6, 6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-        else wg_body_rs<8, 8, 5>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        if (nitw <= 5) wg_body_rs<8, 5, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        else if (nitw <= 6) wg_body_rs<8, 6, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        else wg_body_rs<8, 8, WG_D8B>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
     }
 }
 

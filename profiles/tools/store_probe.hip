@@ -38,6 +38,33 @@ __global__ __launch_bounds__(256) void readall(const u4* src, size_t n_vec, u4* 
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[wave * 64 + lane] = acc;
 }
+// wgrad's access pattern: the buffer is a sequence of records of `rec_kib` KiB (one per 32-sample segment); a workgroup owns a
+// contiguous range of records and each of its 4 waves reads PW 1-KiB pieces of every record (slots wave + 4 pp of the `n_slots`
+// the job touches, spread over the record), D records in flight
+template <int PW, int D>
+__global__ __launch_bounds__(256) void readpat(const char* src, size_t n_rec, int rec_kib, int slot_stride, u4* sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t per = (n_rec + gridDim.x - 1) / gridDim.x, r0 = blockIdx.x * per, r1 = r0 + per < n_rec ? r0 + per : n_rec;
+    u4 acc = {0u, 0u, 0u, 0u};
+    u4 v[D][PW];
+    auto issue = [&](size_t r, int d) {
+        const char* rec = src + (r < r1 ? r : r1 - 1) * (size_t)rec_kib * 1024;
+#pragma unroll
+        for (int pp = 0; pp < PW; ++pp)
+            v[d][pp] = __builtin_nontemporal_load(reinterpret_cast<const u4*>(rec + (size_t)((wave + 4 * pp) * slot_stride) * 1024) + lane);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(r0 + d, d);
+    for (size_t r = r0; r < r1; r += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+#pragma unroll
+            for (int pp = 0; pp < PW; ++pp) acc ^= v[d][pp];
+            issue(r + d + D, d);
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345u) sink[blockIdx.x * 256 + threadIdx.x] = acc;
+}
 int main() {
     const size_t bytes = 2900ull << 20;      // the fine pass' gradient stash
     u4 *a, *b;
@@ -73,5 +100,15 @@ int main() {
     time([&] { readall<32><<<256, 256>>>(a, n, b); }, "read nt, 256 workgroups, 32 KiB in flight per wave", (double)bytes);
     time([&] { readall<16><<<1024, 256>>>(a, n, b); }, "read nt, 1024 workgroups, 16 KiB in flight per wave", (double)bytes);
     time([&] { readall<8><<<4096, 256>>>(a, n, b); }, "read nt, 4096 workgroups, 8 KiB in flight per wave", (double)bytes);
+    {   // 2.9 GB as records of 104 KiB; a "job" reads 32 of their 104 slots (every 3rd KiB) or 32 adjacent ones
+        const int rec_kib = 104;
+        const size_t n_rec = bytes / ((size_t)rec_kib * 1024);
+        const double moved = (double)n_rec * 32 * 1024;
+        time([&] { readpat<8, 2><<<256, 256>>>((const char*)a, n_rec, rec_kib, 3, b); }, "pattern: 32 KiB of every 104 KiB record, pieces 3 KiB apart, D 2", moved);
+        time([&] { readpat<8, 3><<<256, 256>>>((const char*)a, n_rec, rec_kib, 3, b); }, "pattern: the same, D 3", moved);
+        time([&] { readpat<8, 4><<<256, 256>>>((const char*)a, n_rec, rec_kib, 3, b); }, "pattern: the same, D 4", moved);
+        time([&] { readpat<8, 3><<<256, 256>>>((const char*)a, n_rec, rec_kib, 1, b); }, "pattern: 32 adjacent KiB of every 104 KiB record, D 3", moved);
+        time([&] { readpat<8, 3><<<256, 256>>>((const char*)a, n_rec, 32, 1, b); }, "pattern: records of 32 KiB read whole (dense), D 3", (double)(bytes / (32 * 1024)) * 32 * 1024);
+    }
     return 0;
 }
