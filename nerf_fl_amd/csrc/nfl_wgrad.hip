@@ -201,7 +201,7 @@ __device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
 // d_hi (x) h_hi + d_lo (x) h_hi + d_hi (x) h_lo -- one pass over hi + lo instead of three passes of the one-product GEMM.
 template <int PW, int NITW, int D, bool SPLIT = false>
 __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, const int act_slots, const int grd_slots,
-                                           const int seg0, const int seg1, char* smem) {
+                                           const int seg0, const int seg1, const int seg_first, const int seg_step, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave % J.n_wo, wi = wave / J.n_wo;
@@ -232,7 +232,8 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
     wg_u4 R[D][PW];
     auto gload = [&](int seg, auto DD) __attribute__((always_inline)) {
         constexpr int d = decltype(DD)::value;
-        const int sg = seg < seg1 ? seg : seg1 - 1;          // surplus loads re-read the last segment
+        // logical segment `seg` of this workgroup is record seg_first + seg * seg_step of the stashes (see the kernel below)
+        const int sg = seg_first + (seg < seg1 ? seg : seg1 - 1) * seg_step;          // surplus loads re-read the last segment
         const char* bo = A.grd + (size_t)sg * grd_stride;
         const char* bi = A.act + (size_t)sg * act_stride;
 #pragma unroll
@@ -359,38 +360,47 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     int j = 0;
     while (j + 1 < P.n_jobs && (int)blockIdx.x >= A.wg_start[j + 1]) ++j;
     const int part = blockIdx.x - A.wg_start[j], nparts = A.wg_start[j + 1] - A.wg_start[j];
-    const int seg0 = (int)((long long)A.n_seg * part / nparts);
-    const int seg1 = (int)((long long)A.n_seg * (part + 1) / nparts);
+    // The job's workgroups take its segments ROUND-ROBIN (workgroup `part` of `nparts`: records part, part + nparts, ...), not one
+    // contiguous range each: every job crosses the stashes at the same pace (that is what the dealing equalises), so all 256
+    // workgroups then read the same neighbourhood of memory at any time.  Same-box A/B against contiguous ranges
+    // (-DWG_SEGMENTS_CONTIGUOUS): 0.918 vs 0.934 ms per fine pass, the split kernel of f16x3 2.10 vs 2.21
+#ifdef WG_SEGMENTS_CONTIGUOUS
+    const int seg_first = (int)((long long)A.n_seg * part / nparts), seg_step = 1;
+    const int seg0 = 0, seg1 = (int)((long long)A.n_seg * (part + 1) / nparts) - seg_first;
+#else
+    const int seg_first = part, seg_step = nparts;
+    const int seg0 = 0, seg1 = part < A.n_seg ? (A.n_seg - part + nparts - 1) / nparts : 0;
+#endif
     if (seg0 >= seg1) return;
     const WgJob& J = P.job[j];
     const int pw = P.cost[j];
     const int nitw = (J.n_it + J.n_wi - 1) / J.n_wi;       // in tiles per wave
     if constexpr (SPLIT) {      // twice the pieces per segment in flight per set: fewer sets (the registers are the same)
         if (pw <= 4) {
-            if (nitw <= 1) wg_body_rs<8, 1, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-            else wg_body_rs<8, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+            if (nitw <= 1) wg_body_rs<8, 1, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+            else wg_body_rs<8, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
         } else if (pw <= 5) {       // 10 pieces per wave would do; that instantiation gave wrong sums on the GPU (not understood), 12 is verified
-            wg_body_rs<12, 2, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+            wg_body_rs<12, 2, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
         } else if (pw <= 6) {
-            wg_body_rs<12, 4, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+            wg_body_rs<12, 4, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
         } else {
-            if (nitw <= 5) wg_body_rs<16, 5, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-            else if (nitw <= 6) wg_body_rs<16, 6, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-            else wg_body_rs<16, 8, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+            if (nitw <= 5) wg_body_rs<16, 5, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+            else if (nitw <= 6) wg_body_rs<16, 6, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+            else wg_body_rs<16, 8, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
         }
         return;
     }
     if (pw <= 4) {
-        if (nitw <= 1) wg_body_rs<4, 1, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-        else wg_body_rs<4, 2, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        if (nitw <= 1) wg_body_rs<4, 1, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+        else wg_body_rs<4, 2, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
     } else if (pw <= 5) {
-        wg_body_rs<5, 2, WG_D5>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        wg_body_rs<5, 2, WG_D5>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
     } else if (pw <= 6) {          // G of a pass without the transient head: 4 out x 8 in tiles
-        wg_body_rs<6, 4, WG_D6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        wg_body_rs<6, 4, WG_D6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
     } else {
-        if (nitw <= 5) wg_body_rs<8, 5, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-        else if (nitw <= 6) wg_body_rs<8, 6, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
-        else wg_body_rs<8, 8, WG_D8B>(A, J, A.act_rec, A.grd_rec, seg0, seg1, smem);
+        if (nitw <= 5) wg_body_rs<8, 5, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+        else if (nitw <= 6) wg_body_rs<8, 6, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+        else wg_body_rs<8, 8, WG_D8B>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
     }
 }
 
