@@ -108,7 +108,9 @@ int main() {
         time([&] { readpat<8, 3><<<256, 256>>>((const char*)a, n_rec, rec_kib, 3, b); }, "pattern: the same, D 3", moved);
         time([&] { readpat<8, 4><<<256, 256>>>((const char*)a, n_rec, rec_kib, 3, b); }, "pattern: the same, D 4", moved);
         time([&] { readpat<8, 3><<<256, 256>>>((const char*)a, n_rec, rec_kib, 1, b); }, "pattern: 32 adjacent KiB of every 104 KiB record, D 3", moved);
-        time([&] { readpat<8, 3><<<256, 256>>>((const char*)a, n_rec, 32, 1, b); }, "pattern: records of 32 KiB read whole (dense), D 3", (double)(bytes / (32 * 1024)) * 32 * 1024);
+        const size_t n_dense = bytes / (32 * 1024);
+        time([&] { readpat<8, 3><<<256, 256>>>((const char*)a, n_dense, 32, 1, b); }, "pattern: records of 32 KiB read whole (dense), one contiguous range per workgroup, D 3", (double)n_dense * 32 * 1024);
+        time([&] { readpat<8, 2><<<256, 256>>>((const char*)a, n_dense, 32, 1, b); }, "pattern: the same, D 2", (double)n_dense * 32 * 1024);
     }
     return 0;
 }
