@@ -18,10 +18,11 @@
 //                                  and the attribution file's "f16" / "f16w" rows) instead of stochastically
 //   NFL_DIAG_RN_WT                 nfl_pack TU: the transposed weights of the single-image gradient chain are rounded to the NEAREST
 //                                  fp16 (rounds 1-2) instead of stochastically
+//   NFL_DIAG_WGRAD_LDSDMA          nfl_wgrad TU: timing ablation, the load stream by LDS-DMA into the two LDS slots (nothing consumed or flushed)
 //   NFL_DIAG_WGRAD_LOADS_ONLY      nfl_wgrad TU: timing ablation, only the load stream (no LDS round trip, barrier, MFMA): what does the access pattern sustain?
 //   WG_SEGMENTS_CONTIGUOUS / WG_D4 .. WG_D8B   nfl_wgrad TU (variant builds): one contiguous segment range per workgroup; segments in flight per wave
 //   NFL_DIAG_WGRAD_NOFLUSH         nfl_wgrad TU: timing ablation, the workgroups skip their atomic flush (what does the flush cost?)
 #pragma once
-#if (defined(NFL_DIAG_WGRAD_NOFLUSH) || defined(NFL_DIAG_WGRAD_LOADS_ONLY) || defined(NFL_DIAG_RN_DELTA) || defined(NFL_DIAG_RN_WT) || defined(NFL_STAMPS) || defined(NFL_DIAG_X3_PRODS) || defined(NFL_DIAG_WGRAD_PASSES) || defined(NFL_DIAG_INFERENCE_ONLY)) && !defined(NFL_DIAG_BUILD)
+#if (defined(NFL_DIAG_WGRAD_NOFLUSH) || defined(NFL_DIAG_WGRAD_LDSDMA) || defined(NFL_DIAG_WGRAD_LOADS_ONLY) || defined(NFL_DIAG_RN_DELTA) || defined(NFL_DIAG_RN_WT) || defined(NFL_STAMPS) || defined(NFL_DIAG_X3_PRODS) || defined(NFL_DIAG_WGRAD_PASSES) || defined(NFL_DIAG_INFERENCE_ONLY)) && !defined(NFL_DIAG_BUILD)
 #error "diagnostic switches are only for `make diag` / `make variant` (which pass -DNFL_DIAG_BUILD)"
 #endif

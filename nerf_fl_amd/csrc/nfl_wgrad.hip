@@ -262,6 +262,32 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
 #pragma unroll
     for (int b = 0; b < NITW; ++b) it_off[b] = (J.n_ot + my_it[b]) * WG_TSTRIDE;
 
+#ifdef NFL_DIAG_WGRAD_LDSDMA
+    // timing ablation (nfl_diag.h): the same pieces of the same segments, fetched by LDS-DMA (global_load_lds, 16 B per lane) straight
+    // into the two LDS slots instead of through registers; nothing consumes them, nothing is flushed -- what does THAT stream sustain?
+    if (A.n_seg >= 0) {
+        auto dma = [&](int seg) __attribute__((always_inline)) {
+            const int sg = seg_first + (seg < seg1 ? seg : seg1 - 1) * seg_step;
+            const char* bo = A.grd + (size_t)sg * grd_stride;
+            const char* bi = A.act + (size_t)sg * act_stride;
+            char* slot = smem + ((seg - seg0) & 1) * A.slot_bytes;
+#pragma unroll
+            for (int pp = 0; pp < PW; ++pp) {
+                const char* src = (((outmask >> pp) & 1u) ? bo : bi) + poff[pp];
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(slot + (pdst[pp] - lane * 16)), 16, 0, 0);
+            }
+        };
+        dma(seg0);
+        dma(seg0 + 1);
+        for (int seg = seg0; seg < seg1; ++seg) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");      // all but the youngest segment's pieces: `seg` has landed
+            dma(seg + 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+#endif
     wg_static_for<0, D>([&](auto DD) __attribute__((always_inline)) { gload(seg0 + decltype(DD)::value, DD); });
     for (int base = seg0; base < seg1; base += D) {
         wg_static_for<0, D>([&](auto DD) __attribute__((always_inline)) {
