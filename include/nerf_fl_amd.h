@@ -343,15 +343,18 @@ int    nfl_wgrad_plan_build(const nfl_field_desc* desc, int32_t use_transient, v
 /* d_gmax: the same 1024 floats the dgrad of this pass was given (the stashed gradients carry its loss scale).
  * params / d_scratch: xyz_encoding_final is linear, so neither its output nor the gradient w.r.t. its output is ever
  * stashed; the gradients of xyz_encoding_final and of the first 256 input columns of dir_encoding.0 /
- * transient_encoding.0 are composed, in fp32, from G = sum_s delta_dirh (x) h8 (accumulated in d_scratch,
- * nfl_wgrad_scratch_bytes() bytes, overwritten) and the CURRENT fp32 weights of those layers (`params`: the weights the
+ * transient_encoding.0 are composed, in fp32, from G = sum_s delta_dirh (x) h8 (in d_scratch) and the CURRENT fp32 weights of those layers (`params`: the weights the
  * forward pass ran with; weight[NFL_P_FINAL], bias[NFL_P_FINAL], weight[NFL_P_DIR] and, with the transient head,
  * weight[NFL_P_T0] are read).  grads->bias[NFL_P_DIR] (and [NFL_P_T0]) must be given when any composed gradient is.
  * bwd_prec: the value the stashes were sized and written with.  NFL_PREC_F16 / NFL_PREC_F16W: dW = sum_s d_hi (x) h_hi,
  * one streaming pass; NFL_PREC_F16X3: the stashes hold residual records too and every accumulator gets
  * d_hi (x) h_hi + d_lo (x) h_hi + d_hi (x) h_lo in one pass over both (db = sum_s (d_hi + d_lo)).
- * The gradient tensors may be views of one caller-owned flat buffer (nerf_fl_amd.parallel.GradArena): they are zeroed,
- * accumulated and unscaled in place, so a collective can run on that buffer right after this call. */
+ * d_scratch (nfl_wgrad_scratch_bytes() = 68 MB, overwritten; reusable by the next call on the same stream) holds G and the
+ * PARTIAL SUMS of the streaming kernel's workgroups: every workgroup stores its accumulators there and a reduction launch adds
+ * them up in a fixed order, divides by the loss scale and writes the gradient tensors -- the weight and bias gradients are
+ * therefore bit-reproducible from run to run (no atomics), and elements no job owns (heads the call leaves out) are zero.
+ * The gradient tensors may be views of one caller-owned flat buffer (nerf_fl_amd.parallel.GradArena): they are written in
+ * place, so a collective can run on that buffer right after this call. */
 size_t nfl_wgrad_scratch_bytes(void);
 int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash, const char* d_grad_stash,
                   const float* d_gmax, int32_t n_rays, int32_t n_samples, int32_t bwd_prec,

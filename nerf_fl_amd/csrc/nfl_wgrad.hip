@@ -87,7 +87,14 @@ struct WgArgs {
     int wg_start[WG_MAX_JOBS + 1];   // workgroups [wg_start[j], wg_start[j+1]) work on job j
     nfl_field_grads g;
     float* scratch;      // (256, 256): rows 0..127 G (delta_dirh (x) h8), rows 128..255 Gt (delta_g1 (x) h8)
+    // partial sums: workgroup `part` of job j stores its accumulators at partial + part_off[j] + part * part_len[j] (floats), as
+    // [(wave * WG_NOT + a) * part_nitw[j] + b][lane][16] followed by the bias sums [(wave * WG_NOT + a)][lane]; nfl_wgrad_reduce_kernel
+    // adds the parts up in a fixed order, divides by the loss scale and writes the gradient tensors
+    float* partial;
+    int part_off[WG_MAX_JOBS], part_len[WG_MAX_JOBS], part_nitw[WG_MAX_JOBS];
+    int red_start[WG_MAX_JOBS + 1];  // reduction blocks [red_start[j], red_start[j+1]) belong to job j: one per (wave, a, b)
 };
+#define WG_MAX_WGS 256    // workgroups the partial-sum area is sized for (one per CU)
 
 __device__ __forceinline__ int wg_orig(int kind, int i) {
     return kind == NFL_SEG_ACT ? 16 * (i >> 4) + 8 * ((i & 7) >> 2) + 4 * ((i >> 3) & 1) + (i & 3) : i;
@@ -125,38 +132,83 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
 }
 
 template <int NITW>
-__device__ __forceinline__ void wg_flush(const WgArgs& A, const WgJob& J, f16v (&acc)[WG_NOT][NITW], float (&bsum)[WG_NOT],
-                                         const int wo, const int wi, const int lane) {
-    // flush: fp32 atomics into the nn.Linear-layout gradient tensors (still carrying the loss scale: a VALU
-    // multiply here would pull every accumulator through the 256 arch VGPRs and spill inside the streaming
-    // loop; nfl_wgrad_scale_kernel divides the finished tensors instead)
-    const int n = lane & 31, hh = lane >> 5;
+__device__ __forceinline__ void wg_flush(const WgArgs& A, const int j, const int part, f16v (&acc)[WG_NOT][NITW], float (&bsum)[WG_NOT],
+                                         const int wave, const int lane) {
+    // flush: every workgroup stores its accumulators (still carrying the loss scale) as they are, 64 B per lane and tile; the
+    // reduction kernel below knows which gradient element each of them is.  (Until round 3 this was 64 MB of fp32 atomics into
+    // the gradient tensors at the end of the launch, 55 us during which the HBM idled, a zeroing and an unscaling launch around
+    // it -- and a summation order that changed from run to run.)
+    float* P = A.partial + (size_t)A.part_off[j] + (size_t)part * A.part_len[j];
+    typedef float wg_f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int a = 0; a < WG_NOT; ++a) {
-        const int ot = wo * WG_NOT + a;
-        if (ot >= J.n_ot) continue;
-        const WgTile TO = J.ot[ot];
-        const int layer = J.bias_layer_of_ot[ot] >= 0 ? J.bias_layer_of_ot[ot] : J.layer;
-        float* W = layer == WG_SCRATCH ? A.scratch : A.g.weight[layer];
-        wg_static_for<0, NITW>([&](auto B) __attribute__((always_inline)) {
-            constexpr int b = decltype(B)::value;
-            if (wi + b * J.n_wi < J.n_it && W != nullptr) {
-                const WgTile TI = J.it[wi + b * J.n_wi];
-                const int on = wg_orig(TI.kind, n);
-                if (on < TI.nvalid) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int oi = wg_orig(TO.kind, (r & 3) + 8 * (r >> 2) + 4 * hh);
-                        if (oi < TO.nvalid) atomicAdd(W + (size_t)(TO.idx0 + oi) * J.ld + TI.idx0 + on, acc[a][b][r]);
-                    }
-                }
-            }
-        });
-        if (J.do_bias && wi == 0 && layer != WG_SCRATCH && A.g.bias[layer] != nullptr) {
-            const float tot = bsum[a] + __shfl_xor(bsum[a], 32);
-            const int oi = wg_orig(TO.kind, n);
-            if (hh == 0 && oi < TO.nvalid) atomicAdd(A.g.bias[layer] + TO.idx0 + oi, tot);
+        for (int b = 0; b < NITW; ++b) {
+            wg_f4* dst = reinterpret_cast<wg_f4*>(P + ((size_t)((wave * WG_NOT + a) * NITW + b) * 64 + lane) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = wg_f4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
         }
+        P[(size_t)4 * WG_NOT * NITW * 1024 + (wave * WG_NOT + a) * 64 + lane] = bsum[a];
+    }
+}
+
+// One block per (job, wave, a, b) accumulator tile: sums the job's parts in order, unscales, and writes the elements the tile
+// owns -- each gradient element is owned by exactly one tile of one job, so these are plain stores into tensors nobody zeroed.
+__global__ __launch_bounds__(256) void nfl_wgrad_reduce_kernel(const WgArgs A, const float* gmax) {
+    const WgPlan& P = *A.plan;
+    int j = 0;
+    while (j + 1 < P.n_jobs && (int)blockIdx.x >= A.red_start[j + 1]) ++j;
+    const WgJob& J = P.job[j];
+    const int nitw = A.part_nitw[j], t = blockIdx.x - A.red_start[j];
+    const int b = t % nitw, wa = t / nitw, a = wa % WG_NOT, wave = wa / WG_NOT;
+    const int wo = wave % J.n_wo, wi = wave / J.n_wo;
+    const int lane = threadIdx.x & 63, rq = threadIdx.x >> 6;
+    const int nparts = A.wg_start[j + 1] - A.wg_start[j];
+    const int live = A.n_seg < nparts ? A.n_seg : nparts;        // workgroups beyond the segment count returned before their flush
+    float inv;
+    {
+        unsigned v = 0u;
+        for (int i = lane; i < NFL_GMAX_SLOTS; i += 64) {
+            const unsigned o = reinterpret_cast<const unsigned*>(gmax)[i];
+            v = o > v ? o : v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned o = __shfl_xor(v, d);
+            v = o > v ? o : v;
+        }
+        inv = 1.0f / nfl_loss_scale_from_bits(__builtin_amdgcn_readfirstlane(v));
+    }
+    const int ot = wo * WG_NOT + a;
+    if (ot >= J.n_ot) return;
+    const WgTile TO = J.ot[ot];
+    const int layer = J.bias_layer_of_ot[ot] >= 0 ? J.bias_layer_of_ot[ot] : J.layer;
+    const float* base = A.partial + (size_t)A.part_off[j];
+    const int n = lane & 31, hh = lane >> 5;
+    typedef float wg_f4 __attribute__((ext_vector_type(4)));
+    float* W = layer == WG_SCRATCH ? A.scratch : A.g.weight[layer];
+    if (wi + b * J.n_wi < J.n_it && W != nullptr) {
+        const WgTile TI = J.it[wi + b * J.n_wi];
+        const int on = wg_orig(TI.kind, n);
+        wg_f4 sum = {0.f, 0.f, 0.f, 0.f};
+        const float* src = base + ((size_t)((wave * WG_NOT + a) * nitw + b) * 64 + lane) * 16 + 4 * rq;
+        for (int p = 0; p < live; ++p) sum += *reinterpret_cast<const wg_f4*>(src + (size_t)p * A.part_len[j]);
+        if (on < TI.nvalid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * rq + k;
+                const int oi = wg_orig(TO.kind, (r & 3) + 8 * (r >> 2) + 4 * hh);
+                if (oi < TO.nvalid) W[(size_t)(TO.idx0 + oi) * J.ld + TI.idx0 + on] = sum[k] * inv;
+            }
+        }
+    }
+    if (b == 0 && rq == 0 && J.do_bias && wi == 0 && layer != WG_SCRATCH && A.g.bias[layer] != nullptr) {
+        const float* src = base + (size_t)4 * WG_NOT * nitw * 1024 + (wave * WG_NOT + a) * 64 + lane;
+        float sb = 0.f;
+        for (int p = 0; p < live; ++p) sb += src[(size_t)p * A.part_len[j]];
+        const float tot = sb + __shfl_xor(sb, 32);
+        const int oi = wg_orig(TO.kind, n);
+        if (hh == 0 && oi < TO.nvalid) A.g.bias[layer][TO.idx0 + oi] = tot * inv;
     }
 }
 
@@ -201,7 +253,7 @@ __device__ __forceinline__ void wg_landed(wg_u4 (&r)[PW]) {
 // d_hi (x) h_hi + d_lo (x) h_hi + d_hi (x) h_lo -- one pass over hi + lo instead of three passes of the one-product GEMM.
 template <int PW, int NITW, int D, bool SPLIT = false>
 __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, const int act_slots, const int grd_slots,
-                                           const int seg0, const int seg1, const int seg_first, const int seg_step, char* smem) {
+                                           const int seg0, const int seg1, const int seg_first, const int seg_step, const int jidx, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wo = wave % J.n_wo, wi = wave / J.n_wo;
@@ -376,7 +428,7 @@ __device__ __forceinline__ void wg_body_rs(const WgArgs& A, const WgJob& J, cons
         return;
     }
 #endif
-    wg_flush<NITW>(A, J, acc, bsum, wo, wi, lane);
+    wg_flush<NITW>(A, jidx, (int)blockIdx.x - A.wg_start[jidx], acc, bsum, wave, lane);
 }
 
 template <bool SPLIT>
@@ -403,30 +455,30 @@ __global__ __launch_bounds__(256, 1) void nfl_wgrad_kernel(const WgArgs A) {
     const int nitw = (J.n_it + J.n_wi - 1) / J.n_wi;       // in tiles per wave
     if constexpr (SPLIT) {      // twice the pieces per segment in flight per set: fewer sets (the registers are the same)
         if (pw <= 4) {
-            if (nitw <= 1) wg_body_rs<8, 1, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
-            else wg_body_rs<8, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+            if (nitw <= 1) wg_body_rs<8, 1, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
+            else wg_body_rs<8, 2, 4, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
         } else if (pw <= 5) {       // 10 pieces per wave would do; that instantiation gave wrong sums on the GPU (not understood), 12 is verified
-            wg_body_rs<12, 2, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+            wg_body_rs<12, 2, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
         } else if (pw <= 6) {
-            wg_body_rs<12, 4, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+            wg_body_rs<12, 4, 3, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
         } else {
-            if (nitw <= 5) wg_body_rs<16, 5, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
-            else if (nitw <= 6) wg_body_rs<16, 6, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
-            else wg_body_rs<16, 8, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+            if (nitw <= 5) wg_body_rs<16, 5, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
+            else if (nitw <= 6) wg_body_rs<16, 6, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
+            else wg_body_rs<16, 8, 2, true>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
         }
         return;
     }
     if (pw <= 4) {
-        if (nitw <= 1) wg_body_rs<4, 1, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
-        else wg_body_rs<4, 2, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+        if (nitw <= 1) wg_body_rs<4, 1, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
+        else wg_body_rs<4, 2, WG_D4>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
     } else if (pw <= 5) {
-        wg_body_rs<5, 2, WG_D5>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+        wg_body_rs<5, 2, WG_D5>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
     } else if (pw <= 6) {          // G of a pass without the transient head: 4 out x 8 in tiles
-        wg_body_rs<6, 4, WG_D6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+        wg_body_rs<6, 4, WG_D6>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
     } else {
-        if (nitw <= 5) wg_body_rs<8, 5, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
-        else if (nitw <= 6) wg_body_rs<8, 6, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
-        else wg_body_rs<8, 8, WG_D8B>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, smem);
+        if (nitw <= 5) wg_body_rs<8, 5, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
+        else if (nitw <= 6) wg_body_rs<8, 6, WG_D8A>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
+        else wg_body_rs<8, 8, WG_D8B>(A, J, A.act_rec, A.grd_rec, seg0, seg1, seg_first, seg_step, j, smem);
     }
 }
 
@@ -679,7 +731,10 @@ extern "C" int nfl_wgrad_plan_build(const nfl_field_desc* d, int32_t use_transie
     return NFL_OK;
 }
 
-extern "C" size_t nfl_wgrad_scratch_bytes(void) { return (size_t)NFL_W * NFL_W * sizeof(float); }
+extern "C" size_t nfl_wgrad_scratch_bytes(void) {
+    // G (256 x 256) + the partial sums of at most WG_MAX_WGS workgroups with the largest accumulator set (2 x 8 tiles per wave)
+    return ((size_t)NFL_W * NFL_W + (size_t)WG_MAX_WGS * (4 * WG_NOT * 8 * 1024 + 4 * WG_NOT * 64)) * sizeof(float);
+}
 
 extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const char* d_act_stash,
                              const char* d_grad_stash, const float* d_gmax, int32_t n_rays, int32_t n_samples,
@@ -720,7 +775,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     const int nj = hp->n_jobs;
     int total_cost = 0;
     for (int j = 0; j < nj; ++j) total_cost += hp->cost[j];
-    const int budget = ncu;     // one resident workgroup per CU: a second round only repeats the pipeline fill / drain
+    const int budget = ncu < WG_MAX_WGS ? ncu : WG_MAX_WGS;     // one resident workgroup per CU: a second round only repeats the pipeline fill / drain
                                 // (measured 1.06 / 1.14 / 1.23 / 1.32 ms for 1 / 2 / 3 / 4 workgroups per CU)
     // proportional shares rounded down, then the workgroups left over go one at a time to the job whose workgroups
     // carry the most bytes each (every CU gets a workgroup and the slowest job sets the kernel's time)
@@ -746,6 +801,22 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
         acc_wg += n_wg[j];
     }
     A.wg_start[nj] = acc_wg;
+    // partial sums: area of every job's parts behind the G scratch, and the reduction's blocks (one per accumulator tile)
+    A.partial = d_scratch + NFL_W * NFL_W;
+    int part_floats = 0, red_blocks = 0;
+    for (int j = 0; j < nj; ++j) {
+        const int pw = hp->cost[j], nitw = (hp->job[j].n_it + hp->job[j].n_wi - 1) / hp->job[j].n_wi;
+        // the instantiation nfl_wgrad_kernel picks for (pw, nitw): its NITW is the tile count a part stores
+        const int inst = pw <= 4 ? (nitw <= 1 ? 1 : 2) : (pw <= 5 ? 2 : (pw <= 6 ? 4 : (nitw <= 5 ? 5 : (nitw <= 6 ? 6 : 8))));
+        A.part_nitw[j] = inst;
+        A.part_len[j] = 4 * WG_NOT * inst * 1024 + 4 * WG_NOT * 64;
+        A.part_off[j] = part_floats;
+        part_floats += n_wg[j] * A.part_len[j];
+        A.red_start[j] = red_blocks;
+        red_blocks += 4 * WG_NOT * inst;
+    }
+    A.red_start[nj] = red_blocks;
+    if ((size_t)part_floats > (size_t)WG_MAX_WGS * (4 * WG_NOT * 8 * 1024 + 4 * WG_NOT * 64)) return NFL_EINVAL;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nfl_wgrad_kernel<false>),
@@ -769,6 +840,7 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 0, d_gmax);
     if (n_rays == 0) return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 #ifdef NFL_DIAG_WGRAD_PASSES
+#error "NFL_DIAG_WGRAD_PASSES accumulated several launches with the atomic flush; it went with it (last: commit c170289)"
     // diagnostic (nfl_diag.h): the split stashes read by the ONE-product GEMM, hi images only (1) or d_hi + d_lo (2)
     {
         WgArgs B = A;
@@ -787,7 +859,9 @@ extern "C" int nfl_mlp_wgrad(const void* h_wplan, const void* d_wplan, const cha
     if (mult == 2) hipLaunchKernelGGL(nfl_wgrad_kernel<true>, dim3(acc_wg), dim3(256), 2 * A.slot_bytes, s, A);
     else hipLaunchKernelGGL(nfl_wgrad_kernel<false>, dim3(acc_wg), dim3(256), 2 * A.slot_bytes, s, A);
 #endif
-    hipLaunchKernelGGL(nfl_wgrad_scale_kernel, dim3(16, WG_NTENS), dim3(256), 0, s, T, 1, d_gmax);
+    // parts -> gradient tensors and G, summed in a fixed order and divided by the loss scale (what the tensors' zeroing above
+    // still covers: elements no job owns, i.e. the heads a call leaves out)
+    hipLaunchKernelGGL(nfl_wgrad_reduce_kernel, dim3(red_blocks), dim3(256), 0, s, A, d_gmax);
 
     // the composition through xyz_encoding_final (file header); G, db_dir, db_t0 are final (unscaled) by now
     const int W = NFL_W, H = NFL_W / 2;

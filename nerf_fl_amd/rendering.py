@@ -641,23 +641,24 @@ def _backward_pass(field, rays, st, typ, keys, grads, cfg, want_latents, g_rays=
     n_scr = L.nfl_wgrad_scratch_bytes() // 4       # composition scratch (G: include/nerf_fl_amd.h, nfl_mlp_wgrad)
     fg = _lib.FieldGrads()
     views = []
+    # the call's workspace (G + the workgroups' partial sums, 68 MB): one per field, reused by every step
+    if field.wg_scratch is None:
+        field.wg_scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+    scratch = field.wg_scratch
     if arena is not None and all(arena.view(p) is not None for _, w, b in plist for p in (w, b)):
         # the caller's GradArena owns the gradient memory (p.grad are views of it): written in place, nothing returned
-        if field.wg_scratch is None:
-            field.wg_scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
-        scratch = field.wg_scratch
         for i, w, b in plist:
             fg.weight[i], fg.bias[i] = arena.view(w).data_ptr(), arena.view(b).data_ptr()
             views += [None, None]
     else:
-        n_par = sum(w.numel() + b.numel() for _, w, b in plist)
-        scratch = torch.empty(n_scr + n_par, dtype=torch.float32, device=dev)   # zeroed by the call; scratch first (16-byte aligned)
-        off = n_scr
+        n_par = sum((w.numel() + 3) // 4 * 4 + (b.numel() + 3) // 4 * 4 for _, w, b in plist)
+        block = torch.empty(n_par, dtype=torch.float32, device=dev)      # one allocation for the field's gradients (written by the call)
+        off = 0
         for i, w, b in plist:
-            gw = scratch[off:off + w.numel()].view_as(w)
-            off += w.numel()
-            gb = scratch[off:off + b.numel()].view_as(b)
-            off += b.numel()
+            gw = block[off:off + w.numel()].view_as(w)
+            off += (w.numel() + 3) // 4 * 4
+            gb = block[off:off + b.numel()].view_as(b)
+            off += (b.numel() + 3) // 4 * 4
             fg.weight[i], fg.bias[i] = gw.data_ptr(), gb.data_ptr()
             views += [gw, gb]
     h_wp, d_wp = field.wgrad_plan(use_t)

@@ -175,7 +175,8 @@ def test_auxiliary_entry_points_validate_arguments(L):
     assert L.nfl_posenc(None, 4, 10, None, None, None) == -1
     assert L.nfl_composite_backward(None, None) == -1 and L.nfl_mlp_dgrad(None, None, None, None, None) == -1
     assert L.nfl_mlp_wgrad(None, None, None, None, None, 4, 64, 1, None, None, None, None) == -1
-    assert L.nfl_wgrad_scratch_bytes() == 256 * 256 * 4
+    # G (256 x 256) + the partial sums of 256 workgroups x 4 waves x (2 x 8 accumulator tiles x 64 lanes x 16 + 2 x 64 bias sums)
+    assert L.nfl_wgrad_scratch_bytes() == (256 * 256 + 256 * 4 * (2 * 8 * 1024 + 2 * 64)) * 4
     assert L.nfl_pack_fields(0, None, None) == 0                                            # nothing to do
     assert L.nfl_pack_fields(1, None, None) == -1 and L.nfl_pack_fields(_lib.NFL_PACK_MAX_JOBS + 1, None, None) == -1
     assert L.nfl_compose_forward(None, 0, 0, 16, None, None, None, None, None) == -1        # no parameters
