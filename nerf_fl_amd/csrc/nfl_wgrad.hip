@@ -192,7 +192,15 @@ __global__ __launch_bounds__(256) void nfl_wgrad_reduce_kernel(const WgArgs A, c
         const int on = wg_orig(TI.kind, n);
         wg_f4 sum = {0.f, 0.f, 0.f, 0.f};
         const float* src = base + ((size_t)((wave * WG_NOT + a) * nitw + b) * 64 + lane) * 16 + 4 * rq;
-        for (int p = 0; p < live; ++p) sum += *reinterpret_cast<const wg_f4*>(src + (size_t)p * A.part_len[j]);
+        // four parts in flight at a time (a dependent chain of ~20 loads would cost the launch their latencies); the order is fixed
+        const size_t pl = (size_t)A.part_len[j];
+        int p = 0;
+        for (; p + 4 <= live; p += 4) {
+            const wg_f4 v0 = *reinterpret_cast<const wg_f4*>(src + (size_t)p * pl), v1 = *reinterpret_cast<const wg_f4*>(src + (size_t)(p + 1) * pl);
+            const wg_f4 v2 = *reinterpret_cast<const wg_f4*>(src + (size_t)(p + 2) * pl), v3 = *reinterpret_cast<const wg_f4*>(src + (size_t)(p + 3) * pl);
+            sum += (v0 + v1) + (v2 + v3);
+        }
+        for (; p < live; ++p) sum += *reinterpret_cast<const wg_f4*>(src + (size_t)p * pl);
         if (on < TI.nvalid) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
