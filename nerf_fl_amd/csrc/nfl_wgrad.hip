@@ -88,7 +88,7 @@ struct WgArgs {
     nfl_field_grads g;
     float* scratch;      // (256, 256): rows 0..127 G (delta_dirh (x) h8), rows 128..255 Gt (delta_g1 (x) h8)
     // partial sums: workgroup `part` of job j stores its accumulators at partial + part_off[j] + part * part_len[j] (floats), as
-    // [(wave * WG_NOT + a) * part_nitw[j] + b][lane][16] followed by the bias sums [(wave * WG_NOT + a)][lane]; nfl_wgrad_reduce_kernel
+    // [(wave * WG_NOT + a) * part_nitw[j] + b][r / 4][lane][r % 4] followed by the bias sums [(wave * WG_NOT + a)][lane]; nfl_wgrad_reduce_kernel
     // adds the parts up in a fixed order, divides by the loss scale and writes the gradient tensors
     float* partial;
     int part_off[WG_MAX_JOBS], part_len[WG_MAX_JOBS], part_nitw[WG_MAX_JOBS];
@@ -144,9 +144,11 @@ __device__ __forceinline__ void wg_flush(const WgArgs& A, const int j, const int
     for (int a = 0; a < WG_NOT; ++a) {
 #pragma unroll
         for (int b = 0; b < NITW; ++b) {
-            wg_f4* dst = reinterpret_cast<wg_f4*>(P + ((size_t)((wave * WG_NOT + a) * NITW + b) * 64 + lane) * 16);
+            // [tile][q][lane][4]: a store instruction (and a wave of the reduction) covers 1 KiB of contiguous memory
+            float* dst = P + (size_t)((wave * WG_NOT + a) * NITW + b) * 1024 + lane * 4;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dst[q] = wg_f4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<wg_f4*>(dst + q * 256) = wg_f4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
         }
         P[(size_t)4 * WG_NOT * NITW * 1024 + (wave * WG_NOT + a) * 64 + lane] = bsum[a];
     }
@@ -191,14 +193,15 @@ __global__ __launch_bounds__(256) void nfl_wgrad_reduce_kernel(const WgArgs A, c
         const WgTile TI = J.it[wi + b * J.n_wi];
         const int on = wg_orig(TI.kind, n);
         wg_f4 sum = {0.f, 0.f, 0.f, 0.f};
-        const float* src = base + ((size_t)((wave * WG_NOT + a) * nitw + b) * 64 + lane) * 16 + 4 * rq;
-        // four parts in flight at a time (a dependent chain of ~20 loads would cost the launch their latencies); the order is fixed
+        const float* src = base + (size_t)((wave * WG_NOT + a) * nitw + b) * 1024 + rq * 256 + lane * 4;
+        // eight parts in flight at a time (a dependent chain of ~20 loads would cost the launch their latencies); the order is fixed
         const size_t pl = (size_t)A.part_len[j];
         int p = 0;
-        for (; p + 4 <= live; p += 4) {
-            const wg_f4 v0 = *reinterpret_cast<const wg_f4*>(src + (size_t)p * pl), v1 = *reinterpret_cast<const wg_f4*>(src + (size_t)(p + 1) * pl);
-            const wg_f4 v2 = *reinterpret_cast<const wg_f4*>(src + (size_t)(p + 2) * pl), v3 = *reinterpret_cast<const wg_f4*>(src + (size_t)(p + 3) * pl);
-            sum += (v0 + v1) + (v2 + v3);
+        for (; p + 8 <= live; p += 8) {
+            wg_f4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const wg_f4*>(src + (size_t)(p + u) * pl);
+            sum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
         }
         for (; p < live; ++p) sum += *reinterpret_cast<const wg_f4*>(src + (size_t)p * pl);
         if (on < TI.nvalid) {
