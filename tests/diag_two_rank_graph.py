@@ -3,8 +3,8 @@ where does a non-finite value first appear?
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 tests/diag_two_rank_graph.py 4
 Found at the end of round 3: on SOME boxes of the pool (3 of 6 runs on an affected one, 0 of 16 on others) the second replay of the
 forward + backward graph leaves ~95 % of ONE rank's weight gradients non-finite although its loss is finite and every stage is
-followed by a device synchronisation; the library built from the round-2 arithmetic (before the stochastic rounding, the VGPR-form
-MFMAs and the partial-sum weight gradients) shows it at the same rate, a single process replaying the same graphs (13 000 steps)
+followed by a device synchronisation; a library built before the partial-sum weight gradients (atomic flush; already with the stochastic rounding and the
+VGPR-form MFMAs) shows it at the same rate, a single process replaying the same graphs (13 000 steps)
 and the eager two-rank step never do.  Root cause open -- first item for round 4.  Production runs one process per GPU."""
 import os, sys
 import torch, torch.distributed as dist

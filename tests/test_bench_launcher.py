@@ -65,7 +65,7 @@ def test_two_ranks_graphed_step_keeps_replicas_identical():
     parameters must still be bit-identical.
     Up to three attempts: on some boxes of the pool two processes time-sharing ONE GPU intermittently get non-finite gradients
     out of the second graph replay on one rank (tests/diag_two_rank_graph.py: 3 of 6 runs on an affected box, none on others;
-    the same with a library built from the round-2 arithmetic; never with one process per GPU, which is how the product runs --
+    the same with a library built before this round's last wgrad changes; never with one process per GPU, which is how the product runs --
     root cause open).  An attempt that completes must be bit-identical; a non-finite one is repeated and reported."""
     outs = []
     for attempt in range(3):
