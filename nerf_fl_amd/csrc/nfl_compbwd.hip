@@ -171,11 +171,15 @@ __global__ __launch_bounds__(256) void nfl_compbwd_kernel(nfl_compbwd_args a) {
     }
 }
 
+__global__ __launch_bounds__(NFL_GMAX_SLOTS) void nfl_gmax_zero_kernel(float* g) { g[threadIdx.x] = 0.f; }
+
 extern "C" int nfl_composite_backward(const nfl_compbwd_args* a, void* stream) {
     if (!a || !a->d_field_raw || !a->d_z || !a->d_head_grads) return NFL_EINVAL;
     if (a->n_rays < 0 || a->n_samples < 1 || a->n_samples > NFL_CB_MAXN) return NFL_EINVAL;
-    if (a->d_gmax && hipMemsetAsync(a->d_gmax, 0, NFL_GMAX_SLOTS * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
-        return NFL_ELAUNCH;
+    // d_gmax is zeroed by a KERNEL, not hipMemsetAsync: inside a captured HIP graph the memset becomes a memset node, and with a
+    // second process replaying graphs on the same GPU that node was seen to take effect out of order with the kernel that follows
+    // it (the atomicMax results wiped: loss scale from an all-zero maximum, non-finite gradients)
+    if (a->d_gmax) hipLaunchKernelGGL(nfl_gmax_zero_kernel, dim3(1), dim3(NFL_GMAX_SLOTS), 0, static_cast<hipStream_t>(stream), a->d_gmax);
     if (a->n_rays == 0) return NFL_OK;
     hipLaunchKernelGGL(nfl_compbwd_kernel, dim3((a->n_rays + 3) / 4), dim3(256), 0,
                        static_cast<hipStream_t>(stream), *a);

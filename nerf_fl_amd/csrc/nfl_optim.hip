@@ -178,10 +178,14 @@ static int loss_args_ok(const nfl_loss_args* a) {
     return 1;
 }
 
+__global__ void nfl_loss_zero_kernel(float* p) { if (threadIdx.x < 4) p[threadIdx.x] = 0.f; }
+
 extern "C" int nfl_loss_forward(const nfl_loss_args* a, void* stream) {
     if (!loss_args_ok(a) || !a->d_losses) return NFL_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(a->d_losses, 0, 4 * sizeof(float), s) != hipSuccess) return NFL_ELAUNCH;
+    // zeroed by a kernel, not hipMemsetAsync: a memset NODE of a captured graph was seen to take effect out of order with the
+    // kernel after it when a second process replays graphs on the same GPU (nfl_compbwd.hip)
+    hipLaunchKernelGGL(nfl_loss_zero_kernel, dim3(1), dim3(64), 0, s, a->d_losses);
     hipLaunchKernelGGL(nfl_loss_fwd_kernel, dim3(64), dim3(256), 0, s, *a);
     return hipGetLastError() == hipSuccess ? NFL_OK : NFL_ELAUNCH;
 }

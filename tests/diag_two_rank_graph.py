@@ -1,11 +1,11 @@
 """Diagnostic (not a test): two ranks time-sharing ONE GPU over gloo, the step replayed from GraphedTrainStep's two graphs --
 where does a non-finite value first appear?
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29555 tests/diag_two_rank_graph.py 4
-Found at the end of round 3: on SOME boxes of the pool (3 of 6 runs on an affected one, 0 of 16 on others) the second replay of the
-forward + backward graph leaves ~95 % of ONE rank's weight gradients non-finite although its loss is finite and every stage is
-followed by a device synchronisation; a library built before the partial-sum weight gradients (atomic flush; already with the stochastic rounding and the
-VGPR-form MFMAs) shows it at the same rate, a single process replaying the same graphs (13 000 steps)
-and the eager two-rank step never do.  Root cause open -- first item for round 4.  Production runs one process per GPU."""
+Found at the end of round 3: on some boxes the second replay of the forward + backward graph left ~95 % of ONE rank's weight
+gradients non-finite although its loss was finite and every stage is followed by a device synchronisation (5 of 16 runs).  Cause:
+nfl_composite_backward zeroed d_gmax with hipMemsetAsync; captured into a graph that is a memset NODE, and with a second process
+replaying graphs on the same GPU it took effect out of order with the kernel after it (the atomicMax results wiped -> loss scale
+from an all-zero maximum -> overflow).  Zeroed by a kernel instead: 0 of 16 runs.  Kept as the reproducer."""
 import os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
