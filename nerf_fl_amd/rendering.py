@@ -301,7 +301,10 @@ class _PackedField:
             self.fold = {n: (torch.empty_like(params[n + ".weight"], dtype=torch.float32).contiguous(),
                              torch.empty_like(params[n + ".bias"], dtype=torch.float32).contiguous()) for n in names}
         for n in names:
-            self.fold[n][0].copy_(params[n + ".weight"].detach())        # the side columns ride along; the first 256 are overwritten
+            # the side columns ride along; the first 256 are overwritten.  An elementwise KERNEL (x * 1 is exact), not copy_: a
+            # device-to-device copy_ is a hipMemcpyAsync, i.e. a memcpy NODE inside a captured step, and nodes of that kind were seen
+            # to take effect out of order under a second process on the same GPU
+            torch.mul(params[n + ".weight"].detach(), 1.0, out=self.fold[n][0])
         wd, bd = self.fold["dir_encoding.0"]
         wt, bt = self.fold["transient_encoding.0"] if has_t else (None, None)
         n_side = 6 * int(self.desc.n_emb_dir) + 3 + int(self.desc.n_a if self.desc.encode_appearance else 0)
